@@ -1,0 +1,67 @@
+"""ctypes loader for libdmdx.so (the C ABI declared in include/dmdx.h).
+
+The library is built in-tree (``dmd_era5_amd/libdmdx.so``) by
+``__graft_entry__.build()`` / ``make -C dmd_era5_amd/csrc``.  There is no CPU
+fallback: if the shared object is missing, loading raises and every kernel
+entry point of :mod:`dmd_era5_amd.kernels` fails loudly.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdmdx.so")
+
+_i64 = C.c_int64
+_p = C.c_void_p
+_sz = C.c_size_t
+
+# name -> (restype, argtypes); mirrors include/dmdx.h one to one
+SIGNATURES = {
+    "dmdx_version": (C.c_int, []),
+    "dmdx_last_error": (C.c_char_p, []),
+    "dmdx_syrk_workspace_bytes": (_sz, [_i64, _i64]),
+    "dmdx_syrk_f32": (C.c_int, [_p, _i64, _i64, _i64, _p, _i64, _p, _i64, _p, _sz, _p]),
+    "dmdx_gemm_tn_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "dmdx_gemm_tn_f32": (
+        C.c_int,
+        [_p, _i64, _p, _i64, _i64, _i64, _i64, _p, _i64, _p, _i64, _p, _sz, _p],
+    ),
+    "dmdx_gemm_nn_skinny_f32": (C.c_int, [_p, _i64, _i64, _i64, _p, _i64, _i64, _p, _i64, _p]),
+    "dmdx_row_center_scale_f32": (C.c_int, [_p, _i64, _i64, _i64, _p, _p, C.c_int, _p]),
+    "dmdx_delay_shift_sum_f64": (C.c_int, [_p, _i64, _i64, C.c_int, _p, _i64, _p, _i64, _p]),
+    "dmdx_scale_columns_f32": (C.c_int, [_p, _i64, _i64, _i64, _p, _p]),
+}
+
+_lib = None
+
+
+class DmdxError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load libdmdx.so once; raise if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DmdxError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` or `make -C dmd_era5_amd/csrc` (there is no CPU fallback)."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().dmdx_last_error().decode("utf-8", "replace")
+        raise DmdxError(f"{what} failed (rc={rc}): {msg}")

@@ -1,0 +1,40 @@
+// Shared declarations for the libdmdx.so translation units (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/dmdx.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+void dmdx_set_error(const char* fmt, ...);
+
+#define DMDX_CHECK_ARG(cond, ...)        \
+  do {                                   \
+    if (!(cond)) {                       \
+      dmdx_set_error(__VA_ARGS__);       \
+      return DMDX_E_INVALID;             \
+    }                                    \
+  } while (0)
+
+#define DMDX_HIP(expr)                                                        \
+  do {                                                                        \
+    hipError_t e_ = (expr);                                                   \
+    if (e_ != hipSuccess) {                                                   \
+      dmdx_set_error("%s failed: %s", #expr, hipGetErrorString(e_));          \
+      return -(int)e_;                                                        \
+    }                                                                         \
+  } while (0)
+
+#define DMDX_LAUNCH_CHECK()                                                   \
+  do {                                                                        \
+    hipError_t e_ = hipGetLastError();                                        \
+    if (e_ != hipSuccess) {                                                   \
+      dmdx_set_error("kernel launch failed: %s", hipGetErrorString(e_));      \
+      return -(int)e_;                                                        \
+    }                                                                         \
+  } while (0)
+
+static inline bool dmdx_aligned16(const void* p) { return ((uintptr_t)p & 15u) == 0; }

@@ -1,0 +1,178 @@
+"""Python face of the C ABI (include/dmdx.h): torch tensors in, torch tensors out.
+
+Layout convention used everywhere in this package
+-------------------------------------------------
+The C ABI is column-major ``(ptr, rows, cols, ld)``.  A column-major matrix
+``M`` (rows x cols) is held on the device as the torch tensor ``Mt`` of shape
+``(cols, rows)`` with strides ``(ld, 1)`` -- i.e. the row-major transpose, so
+``Mt[j, i] == M[i, j]``.  The snapshot matrix X (space x time) is therefore a
+``(time, space)`` tensor: one snapshot per row, exactly the order an ERA5
+NetCDF slice is stored in.  The delay-embedded matrix (reference
+slice_tools.py:207-211) is the overlapping view
+``Xt.as_strided((n-d+1, d*m), (m, 1))`` -- zero copy.
+
+PyTorch is plumbing here (device memory, streams); the arithmetic is in
+libdmdx.so.  There is no CPU fallback: every method raises if the library or
+the GPU is missing.
+"""
+
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+
+
+def _ptr(t: torch.Tensor | None) -> int | None:
+    return None if t is None else t.data_ptr()
+
+
+def _check_mat(t: torch.Tensor, dtype, name: str) -> tuple[int, int, int]:
+    """-> (rows, cols, ld) of the column-major matrix a (cols, rows) tensor holds."""
+    if not t.is_cuda:
+        raise _lib.DmdxError(f"{name}: expected a device tensor (no CPU fallback exists)")
+    if t.dtype != dtype or t.dim() != 2:
+        raise _lib.DmdxError(f"{name}: expected 2-D {dtype}, got {t.dtype} {tuple(t.shape)}")
+    if t.shape[1] > 1 and t.stride(1) != 1:
+        raise _lib.DmdxError(f"{name}: inner stride must be 1, got {t.stride()}")
+    ld = t.stride(0) if t.shape[0] > 1 else max(t.shape[1], 1)
+    return t.shape[1], t.shape[0], ld
+
+
+class HipKernels:
+    """The product kernel provider (libdmdx.so on the current CUDA/HIP device)."""
+
+    name = "hip"
+
+    def __init__(self):
+        self._lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.DmdxError("no HIP device visible: the dmdx kernels have no CPU fallback")
+        self._ws: dict[int, torch.Tensor] = {}
+        # when set to a list, every launch is bracketed by HIP events on the launch
+        # stream and (name, shape, start, stop) is appended (bench.py reads these)
+        self.events: list | None = None
+
+    # -- plumbing ---------------------------------------------------------
+    def _stream(self) -> int:
+        return torch.cuda.current_stream().cuda_stream
+
+    def _timed(self, name: str, shape: tuple, fn):
+        if self.events is None:
+            return fn()
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = fn()
+        e1.record()
+        self.events.append((name, shape, e0, e1))
+        return rc
+
+    def _workspace(self, device: torch.device, nbytes: int) -> torch.Tensor:
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        ws = self._ws.get(idx)
+        if ws is None or ws.numel() < nbytes:
+            self._ws[idx] = ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=device)
+        return ws
+
+    # -- K1 -----------------------------------------------------------------
+    def syrk(self, Xt: torch.Tensor, want32: bool = False):
+        """G = X^T X (fp64, both triangles).  Xt: (n, m) fp32.  -> G64 [, G32]."""
+        m, n, ld = _check_mat(Xt, torch.float32, "syrk X")
+        G64 = torch.empty((n, n), dtype=torch.float64, device=Xt.device)
+        G32 = torch.empty((n, n), dtype=torch.float32, device=Xt.device) if want32 else None
+        nbytes = self._lib.dmdx_syrk_workspace_bytes(m, n)
+        ws = self._workspace(Xt.device, nbytes)
+        rc = self._timed("syrk", (m, n), lambda: self._lib.dmdx_syrk_f32(
+            _ptr(Xt), m, n, ld, _ptr(G64), n, _ptr(G32), n, _ptr(ws), ws.numel(), self._stream()
+        ))
+        _lib.check(rc, "dmdx_syrk_f32")
+        return (G64, G32) if want32 else G64
+
+    # -- K3 -----------------------------------------------------------------
+    def gemm_tn(self, At: torch.Tensor, Bt: torch.Tensor, want32: bool = False):
+        """C = A^T B for K-contiguous A (K x na), B (K x nb).
+
+        At: (na, K), Bt: (nb, K) fp32.  Returns Ct of shape (nb, na) (the
+        column-major na x nb C), fp64 [and fp32]."""
+        Ka, na, lda = _check_mat(At, torch.float32, "gemm_tn A")
+        Kb, nb, ldb = _check_mat(Bt, torch.float32, "gemm_tn B")
+        if Ka != Kb:
+            raise _lib.DmdxError(f"gemm_tn: K mismatch {Ka} vs {Kb}")
+        C64 = torch.empty((nb, na), dtype=torch.float64, device=At.device)
+        C32 = torch.empty((nb, na), dtype=torch.float32, device=At.device) if want32 else None
+        nbytes = self._lib.dmdx_gemm_tn_workspace_bytes(Ka, na, nb)
+        ws = self._workspace(At.device, nbytes)
+        rc = self._timed("gemm_tn", (Ka, na, nb), lambda: self._lib.dmdx_gemm_tn_f32(
+            _ptr(At), lda, _ptr(Bt), ldb, Ka, na, nb, _ptr(C64), na, _ptr(C32), na,
+            _ptr(ws), ws.numel(), self._stream(),
+        ))
+        _lib.check(rc, "dmdx_gemm_tn_f32")
+        return (C64, C32) if want32 else C64
+
+    # -- K2 -----------------------------------------------------------------
+    def skinny(self, Xt: torch.Tensor, Wt: torch.Tensor) -> torch.Tensor:
+        """Y = X W.  Xt: (n, m), Wt: (l, n) fp32 -> Yt: (l, m) fp32."""
+        m, n, ldx = _check_mat(Xt, torch.float32, "skinny X")
+        nw, l, ldw = _check_mat(Wt, torch.float32, "skinny W")
+        if nw != n:
+            raise _lib.DmdxError(f"skinny: W has {nw} rows, X has {n} columns")
+        Yt = torch.empty((l, m), dtype=torch.float32, device=Xt.device)
+        rc = self._timed("skinny", (m, n, l), lambda: self._lib.dmdx_gemm_nn_skinny_f32(
+            _ptr(Xt), m, n, ldx, _ptr(Wt), ldw, l, _ptr(Yt), m, self._stream()
+        ))
+        _lib.check(rc, "dmdx_gemm_nn_skinny_f32")
+        return Yt
+
+    # -- K5 -----------------------------------------------------------------
+    def row_center_scale_(self, Xt: torch.Tensor, scale: bool):
+        """In place: subtract the per-space-point mean over time (and divide by the
+        std, ddof 0).  Xt: (n, m).  -> (mean (m,), std (m,) or None)."""
+        m, n, ldx = _check_mat(Xt, torch.float32, "row_center_scale X")
+        mean = torch.empty(m, dtype=torch.float32, device=Xt.device)
+        std = torch.empty(m, dtype=torch.float32, device=Xt.device) if scale else None
+        rc = self._timed("row_center_scale", (m, n), lambda: self._lib.dmdx_row_center_scale_f32(
+            _ptr(Xt), m, n, ldx, _ptr(mean), _ptr(std), int(bool(scale)), self._stream()
+        ))
+        _lib.check(rc, "dmdx_row_center_scale_f32")
+        return mean, std
+
+    # -- K6 -----------------------------------------------------------------
+    def delay_shift_sum(self, G64: torch.Tensor, d: int, want32: bool = False):
+        """Gd[i, j] = sum_{k<d} G[i+k, j+k]."""
+        if G64.dtype != torch.float64 or G64.dim() != 2 or G64.shape[0] != G64.shape[1]:
+            raise _lib.DmdxError("delay_shift_sum: expected a square fp64 matrix")
+        if not G64.is_cuda or not G64.is_contiguous():
+            raise _lib.DmdxError("delay_shift_sum: expected a contiguous device tensor")
+        n = G64.shape[0]
+        nd = n - d + 1
+        Gd = torch.empty((nd, nd), dtype=torch.float64, device=G64.device)
+        Gd32 = torch.empty((nd, nd), dtype=torch.float32, device=G64.device) if want32 else None
+        rc = self._lib.dmdx_delay_shift_sum_f64(
+            _ptr(G64), n, n, int(d), _ptr(Gd), nd, _ptr(Gd32), nd, self._stream()
+        )
+        _lib.check(rc, "dmdx_delay_shift_sum_f64")
+        return (Gd, Gd32) if want32 else Gd
+
+    # -- helper -------------------------------------------------------------
+    def scale_columns_(self, Yt: torch.Tensor, alpha: torch.Tensor) -> torch.Tensor:
+        """Y[:, j] *= alpha[j]  (Yt: (l, m), alpha: (l,) fp32)."""
+        m, l, ldy = _check_mat(Yt, torch.float32, "scale_columns Y")
+        if alpha.dtype != torch.float32 or alpha.numel() != l or not alpha.is_cuda:
+            raise _lib.DmdxError("scale_columns: alpha must be a device fp32 vector of length l")
+        rc = self._lib.dmdx_scale_columns_f32(
+            _ptr(Yt), m, l, ldy, _ptr(alpha.contiguous()), self._stream()
+        )
+        _lib.check(rc, "dmdx_scale_columns_f32")
+        return Yt
+
+
+_default: HipKernels | None = None
+
+
+def default_kernels() -> HipKernels:
+    """The process-wide HIP kernel provider (raises if library / GPU is missing)."""
+    global _default
+    if _default is None:
+        _default = HipKernels()
+    return _default

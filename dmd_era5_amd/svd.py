@@ -1,0 +1,374 @@
+"""Rank-r SVD of the (space x time) snapshot matrix on MI355X.
+
+Replaces the two CPU calls of the reference's ``svd_on_era5``
+(/root/reference/src/dmd_era5/era5_svd/era5_svd.py:249-259):
+
+* ``svd_type == "standard"``  (reference: ``np.linalg.svd`` then slice, :251-254)
+  -> :func:`svd_snapshots`: method of snapshots.  One pass of X through the
+  fp32-MFMA Gram kernel (K1), the small eigenproblem of the n x n Gram in
+  fp64, one pass of X through the tall-skinny projection kernel (K2), and a
+  Rayleigh-Ritz refinement on the projected basis (a Gram of the m x l basis,
+  l ~ r, which restores the relative accuracy of the small singular values).
+* ``svd_type == "randomized"`` (reference: sklearn ``randomized_svd`` with all
+  defaults, :258; algorithm extmath.py:287-357,531-604) -> :func:`svd_randomized`:
+  the same range finder / power iterations, with the tall LU/QR normalisers
+  replaced by CholeskyQR (an l x l Gram + triangular solve) -- the iterates
+  span the same subspaces, so U, s, V agree up to rounding for the same Omega.
+
+Data layout: see :mod:`dmd_era5_amd.kernels` -- the snapshot matrix is the
+``(time, space)`` fp32 tensor ``Xt``; with row sharding every rank holds
+``Xt[:, rows_of_this_rank]`` and the only exchanges are sum-all-reduces of
+small matrices (n x n Gram, n x l, l x l) through ``comm``.
+
+Everything dense and small (eigh / cholesky / qr / svd of matrices with at most
+n ~ 10^4 rows) runs in fp64 through torch on the same device.
+"""
+
+from __future__ import annotations
+
+import math
+import time
+from dataclasses import dataclass, field
+
+import numpy as np
+import torch
+
+__all__ = [
+    "Comm",
+    "TorchDistComm",
+    "SvdResult",
+    "embed_view",
+    "top_eigh",
+    "svd_snapshots",
+    "svd_randomized",
+]
+
+
+# ---------------------------------------------------------------------------
+# communication (row shards): sum all-reduce of small dense matrices only
+# ---------------------------------------------------------------------------
+class Comm:
+    """Single-rank communicator (no-op)."""
+
+    world_size = 1
+    rank = 0
+
+    def allreduce_sum_(self, t: torch.Tensor) -> torch.Tensor:
+        return t
+
+    def allgather(self, t: torch.Tensor) -> list[torch.Tensor]:
+        return [t]
+
+
+class TorchDistComm(Comm):
+    """torch.distributed communicator: backend "nccl" is RCCL over xGMI on ROCm;
+    "gloo" is used by the CPU tests."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+
+        self._dist = dist
+        self._group = group
+        self.world_size = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+
+    def allreduce_sum_(self, t: torch.Tensor) -> torch.Tensor:
+        if self.world_size > 1:
+            self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self._group)
+        return t
+
+    def allgather(self, t: torch.Tensor) -> list[torch.Tensor]:
+        if self.world_size == 1:
+            return [t]
+        out = [torch.empty_like(t) for _ in range(self.world_size)]
+        self._dist.all_gather(out, t.contiguous(), group=self._group)
+        return out
+
+
+@dataclass
+class SvdResult:
+    Ut: torch.Tensor  # (k, M_local) fp32: row j = left singular vector j (local rows)
+    s: torch.Tensor   # (k,) fp64
+    Vh: torch.Tensor  # (k, n_eff) fp64: row j = right singular vector j
+    info: dict = field(default_factory=dict)
+
+
+def _kern(kern):
+    if kern is not None:
+        return kern
+    from .kernels import default_kernels
+
+    return default_kernels()
+
+
+def embed_view(Xt: torch.Tensor, d: int) -> torch.Tensor:
+    """Zero-copy delay embedding (reference slice_tools.py:207-211): row
+    ``k*m + s`` of the embedded matrix is ``X[s, t+k]``."""
+    if d == 1:
+        return Xt
+    n, m = Xt.shape
+    if not Xt.is_contiguous():
+        raise ValueError("delay embedding view needs a contiguous (time, space) tensor")
+    if d > n:
+        raise ValueError(f"delay embedding {d} exceeds the number of snapshots {n}")
+    return Xt.as_strided((n - d + 1, d * m), (m, 1))
+
+
+# ---------------------------------------------------------------------------
+# small dense pieces (fp64, torch)
+# ---------------------------------------------------------------------------
+def _orth(Y: torch.Tensor) -> torch.Tensor:
+    Q, _ = torch.linalg.qr(Y, mode="reduced")
+    return Q
+
+
+def top_eigh(G: torch.Tensor, l: int, method: str = "auto", tol: float = 1e-11,
+             max_outer: int = 40, info: dict | None = None):
+    """Largest ``l`` eigenpairs of the symmetric PSD fp64 matrix ``G`` (n x n),
+    eigenvalues descending.
+
+    ``full``: torch.linalg.eigh.  ``krylov``: restarted block Krylov with
+    Rayleigh-Ritz (only products G @ block, thin QRs and a (3b x 3b) eigh), run
+    until every wanted pair has residual <= tol * lambda_1, falling back to the
+    full solver if that does not happen.  ``auto`` picks by size.
+    """
+    n = G.shape[0]
+    l = min(l, n)
+    if method == "auto":
+        method = "full" if (n <= 1536 or 4 * l >= n) else "krylov"
+    if method == "full":
+        lam, V = torch.linalg.eigh(G)
+        lam = torch.flip(lam[-l:], dims=(0,))
+        V = torch.flip(V[:, -l:], dims=(1,))
+        if info is not None:
+            info["eig_method"] = "full"
+        return lam, V.contiguous()
+
+    b = min(n // 3, l + max(8, l // 4))
+    gen = torch.Generator(device="cpu").manual_seed(1234)
+    Q = torch.randn((n, b), dtype=torch.float64, generator=gen).to(G.device)
+    Q = _orth(G @ Q)
+    lam = V = None
+    for it in range(max_outer):
+        Y1 = _orth(G @ Q)
+        Y2 = G @ Y1
+        S = _orth(torch.cat([Q, Y1, Y2], dim=1))
+        GS = G @ S
+        T = S.T @ GS
+        T = 0.5 * (T + T.T)
+        th, Z = torch.linalg.eigh(T)
+        th = torch.flip(th, dims=(0,))[:b]
+        Z = torch.flip(Z, dims=(1,))[:, :b]
+        Q = S @ Z
+        R = GS @ Z[:, :l] - Q[:, :l] * th[:l]
+        res = torch.linalg.vector_norm(R, dim=0).max() / th[0].abs().clamp_min(1e-300)
+        lam, V = th[:l], Q[:, :l]
+        if float(res) <= tol:
+            if info is not None:
+                info["eig_method"] = "krylov"
+                info["eig_outer_iters"] = it + 1
+                info["eig_residual"] = float(res)
+            return lam.contiguous(), V.contiguous()
+    if info is not None:
+        info["eig_krylov_failed_residual"] = float(res)
+    return top_eigh(G, l, method="full", info=info)
+
+
+def _sign_flip(Ut: torch.Tensor, Vh: torch.Tensor, comm: Comm, kern):
+    """u-based sign convention of sklearn's svd_flip (extmath.py:935-943): the
+    largest-|.| entry of every left singular vector becomes positive."""
+    idx = Ut.abs().argmax(dim=1, keepdim=True)
+    val = Ut.gather(1, idx).squeeze(1)
+    if comm.world_size > 1:
+        allv = torch.stack(comm.allgather(val.contiguous()), dim=0)  # (world, k)
+        pick = allv.abs().argmax(dim=0, keepdim=True)
+        val = allv.gather(0, pick).squeeze(0)
+    sign = torch.where(val < 0, -torch.ones_like(val), torch.ones_like(val))
+    kern.scale_columns_(Ut, sign.to(torch.float32))
+    Vh = Vh * sign.to(Vh.dtype)[:, None]
+    return Ut, Vh
+
+
+def _sync_time(device) -> float:
+    if device.type == "cuda":
+        torch.cuda.synchronize(device)
+    return time.perf_counter()
+
+
+# ---------------------------------------------------------------------------
+# "standard": method of snapshots
+# ---------------------------------------------------------------------------
+def svd_snapshots(Xt: torch.Tensor, n_components: int, delay: int = 1, oversample: int | None = None,
+                  refine: bool = True, flip_sign: bool = True, comm: Comm | None = None,
+                  kern=None, eig_method: str = "auto", timings: bool = False) -> SvdResult:
+    """Rank-k SVD of the (delay-embedded) snapshot matrix by the Gram route.
+
+    Xt: (n, m_local) fp32 device tensor, already pre-processed (centred/scaled).
+    Returns local rows of U; s and V are replicated on every rank.
+    """
+    kern = _kern(kern)
+    comm = comm or Comm()
+    info: dict = {}
+    dev = Xt.device
+    t0 = _sync_time(dev) if timings else 0.0
+
+    G = kern.syrk(Xt)
+    comm.allreduce_sum_(G)
+    if delay > 1:
+        G = kern.delay_shift_sum(G, delay)
+    nd = G.shape[0]
+    t1 = _sync_time(dev) if timings else 0.0
+
+    Mg = Xt.shape[1] * delay
+    if comm.world_size > 1:
+        tot = torch.tensor([Mg], dtype=torch.int64, device=dev)
+        comm.allreduce_sum_(tot)
+        Mg = int(tot.item())
+    k = min(n_components, nd, Mg)  # np.linalg.svd(full_matrices=False)[:k]
+    p = oversample if oversample is not None else max(8, k // 4)
+    l = min(nd, k + p) if refine else k
+    lam, V = top_eigh(G, l, method=eig_method, info=info)
+    lam1 = lam[0].clamp_min(1e-300)
+    good = lam > lam1 * 1e-14
+    s0 = torch.sqrt(torch.where(good, lam, torch.ones_like(lam)))
+    inv_s0 = torch.where(good, 1.0 / s0, torch.zeros_like(s0))
+    s0 = torch.where(good, s0, torch.zeros_like(s0))
+    t2 = _sync_time(dev) if timings else 0.0
+
+    Et = embed_view(Xt, delay)
+    Wt = (V * inv_s0).T.contiguous().to(torch.float32)  # (l, nd)
+    Upt = kern.skinny(Et, Wt)                            # (l, M): U' = X V S^-1
+    t3 = _sync_time(dev) if timings else 0.0
+
+    if refine:
+        # Rayleigh-Ritz in span(V): (XV)^T (XV) = S (U'^T U') S, graded by S so the
+        # small singular values keep their relative accuracy.
+        Mm = kern.syrk(Upt)                              # (l, l) fp64
+        comm.allreduce_sum_(Mm)
+        T = s0[:, None] * Mm * s0[None, :]
+        T = 0.5 * (T + T.T)
+        mu, Z = torch.linalg.eigh(T)
+        mu = torch.flip(mu, dims=(0,))[:k]
+        Z = torch.flip(Z, dims=(1,))[:, :k]
+        s = torch.sqrt(mu.clamp_min(0.0))
+        ok = s > s0[0] * 1e-7
+        inv_s = torch.where(ok, 1.0 / torch.where(ok, s, torch.ones_like(s)), torch.zeros_like(s))
+        Rm = (s0[:, None] * Z) * inv_s[None, :]          # (l, k): U = U' R
+        Ut = kern.skinny(Upt, Rm.T.contiguous().to(torch.float32))  # (k, M)
+        Vh = (V @ Z).T.contiguous()
+    else:
+        s = s0[:k]
+        Ut = Upt[:k]
+        Vh = V[:, :k].T.contiguous()
+    if flip_sign:
+        Ut, Vh = _sign_flip(Ut, Vh, comm, kern)
+    if timings:
+        t4 = _sync_time(dev)
+        info.update(t_gram=t1 - t0, t_eig=t2 - t1, t_project=t3 - t2, t_refine=t4 - t3,
+                    t_total=t4 - t0)
+    info.update(l=l, k=k, nd=nd)
+    return SvdResult(Ut=Ut, s=s, Vh=Vh, info=info)
+
+
+# ---------------------------------------------------------------------------
+# "randomized": sklearn's range finder with CholeskyQR normalisers
+# ---------------------------------------------------------------------------
+def _cholqr(Yt: torch.Tensor, comm: Comm, kern, passes: int = 1) -> torch.Tensor:
+    """Orthonormalise the columns of the tall matrix Y (Yt: (l, M)): G = Y^T Y
+    (l x l, all-reduced), G = R^T R, Y <- Y R^-1."""
+    l = Yt.shape[0]
+    eye = torch.eye(l, dtype=torch.float64, device=Yt.device)
+    for _ in range(passes):
+        G = kern.syrk(Yt)
+        comm.allreduce_sum_(G)
+        G = 0.5 * (G + G.T)
+        L, err = torch.linalg.cholesky_ex(G)
+        if int(err) != 0:  # numerically rank deficient: shift (keeps the span)
+            shift = 1e-12 * torch.diagonal(G).sum()
+            L = torch.linalg.cholesky(G + shift * eye)
+        Rinv = torch.linalg.solve_triangular(L.T, eye, upper=True)  # R = L^T
+        Yt = kern.skinny(Yt, Rinv.T.contiguous().to(torch.float32))
+    return Yt
+
+
+def resolve_n_iter(n_components: int, m: int, n: int, n_iter="auto") -> int:
+    """extmath.py:557-560."""
+    if n_iter == "auto":
+        return 7 if n_components < 0.1 * min(m, n) else 4
+    return int(n_iter)
+
+
+def svd_randomized(Xt: torch.Tensor, n_components: int, delay: int = 1, n_oversamples: int = 10,
+                   n_iter="auto", power_iteration_normalizer: str = "auto",
+                   omega: np.ndarray | torch.Tensor | None = None, random_state=None,
+                   flip_sign: bool = True, comm: Comm | None = None, kern=None,
+                   timings: bool = False) -> SvdResult:
+    """Randomized SVD (Halko et al.) as sklearn runs it for m >= n.
+
+    omega: optional (n_eff, k+p) test matrix; default
+    ``RandomState(random_state).normal(size=(n_eff, k+p))`` -- the very draw
+    sklearn makes (extmath.py:297), so a seeded run is comparable entry by entry.
+    """
+    kern = _kern(kern)
+    comm = comm or Comm()
+    info: dict = {}
+    dev = Xt.device
+    Et = embed_view(Xt, delay)
+    nd, M = Et.shape
+    Mg = M
+    if comm.world_size > 1:
+        tot = torch.tensor([M], dtype=torch.int64, device=dev)
+        comm.allreduce_sum_(tot)
+        Mg = int(tot.item())
+    if Mg < nd:
+        raise ValueError("svd_randomized expects a tall matrix (space >= time); "
+                         "transpose first (see svd_device)")
+    k = min(n_components, nd)
+    l = min(nd, n_components + n_oversamples)
+    n_it = resolve_n_iter(n_components, Mg, nd, n_iter)
+    if power_iteration_normalizer == "auto":
+        power_iteration_normalizer = "none" if n_it <= 2 else "LU"
+    # The iterates are ALWAYS re-orthonormalised (CholeskyQR is stable only for
+    # moderately conditioned blocks, and it costs two passes over an m x l matrix,
+    # nothing next to a pass over X).  In exact arithmetic this spans the same
+    # subspaces as sklearn's "none" / "LU" / "QR" choices; the argument is kept for
+    # API parity and recorded in info.
+    normalise = True
+    if omega is None:
+        rs = random_state if isinstance(random_state, np.random.RandomState) else \
+            np.random.RandomState(random_state)
+        omega = rs.normal(size=(nd, n_components + n_oversamples))[:, :l]
+    if isinstance(omega, np.ndarray):
+        omega = torch.from_numpy(np.ascontiguousarray(omega.T, dtype=np.float32))
+        Qt = omega.to(dev)
+    else:
+        Qt = omega.T.contiguous().to(device=dev, dtype=torch.float32)
+    if tuple(Qt.shape) != (l, nd):
+        raise ValueError(f"omega must be ({nd}, {l}), got {tuple(Qt.shape)[::-1]}")
+    t0 = _sync_time(dev) if timings else 0.0
+
+    for _ in range(n_it):
+        Yt = kern.skinny(Et, Qt)                 # Y = X Q            (extmath.py:350)
+        if normalise:
+            Yt = _cholqr(Yt, comm, kern)
+        Zt = kern.gemm_tn(Et, Yt)                # Z = X^T Y, (l, nd) (extmath.py:351)
+        comm.allreduce_sum_(Zt)
+        if normalise:
+            Qt = _orth(Zt.T).T.contiguous().to(torch.float32)
+        else:
+            Qt = Zt.to(torch.float32)
+    Yt = kern.skinny(Et, Qt)                     # extmath.py:355
+    Qmt = _cholqr(Yt, comm, kern, passes=2)      # orthonormal basis of range(Y)
+    Bm = kern.gemm_tn(Et, Qmt)                   # (l, nd) = Q^T X    (extmath.py:577)
+    comm.allreduce_sum_(Bm)
+    Uhat, s, Vh = torch.linalg.svd(Bm, full_matrices=False)
+    Ut = kern.skinny(Qmt, Uhat[:, :k].T.contiguous().to(torch.float32))  # U = Q Uhat
+    s = s[:k]
+    Vh = Vh[:k].contiguous()
+    if flip_sign:
+        Ut, Vh = _sign_flip(Ut, Vh, comm, kern)
+    if timings:
+        info["t_total"] = _sync_time(dev) - t0
+    info.update(l=l, k=k, nd=nd, n_iter=n_it, normalizer=power_iteration_normalizer,
+                passes_over_X=2 * n_it + 2)
+    return SvdResult(Ut=Ut, s=s, Vh=Vh, info=info)

@@ -1,0 +1,101 @@
+/*
+ * dmdx.h -- C ABI of libdmdx.so, the MI355X (gfx950) kernels behind the
+ * ERA5 snapshot-matrix SVD hot path.
+ *
+ * What it replaces in the reference (ClimeTrend/DMD-ERA5, paths relative to
+ * the reference root): the reference has no FFI; its hot loop is two
+ * third-party CPU calls made from
+ *     src/dmd_era5/era5_svd/era5_svd.py:251   np.linalg.svd(X, full_matrices=False)
+ *     src/dmd_era5/era5_svd/era5_svd.py:258   sklearn randomized_svd(X, n_components)
+ * plus the pre-processing passes that build X
+ *     src/dmd_era5/slice_tools/slice_tools.py:171-179  (mean / std / centre / scale)
+ *     src/dmd_era5/slice_tools/slice_tools.py:207-211  (delay embedding)
+ * Each entry point below names the reference line whose arithmetic it takes
+ * over.  The Python host (dmd_era5_amd/) binds these with ctypes and keeps the
+ * reference's function signatures (svd_on_era5, main, ...).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HBM) unless named host_*;
+ *   - matrices are COLUMN-MAJOR with a leading dimension in elements,
+ *     (ptr, rows, cols, ld); rows > ld is allowed for the input X only: that is
+ *     the zero-copy delay-embedding view E[k*m+s, t] = X[s, t+k] = ptr[(k*m+s) + t*ld]
+ *     with ld = m (slice_tools.py:207-211);
+ *   - stream is a hipStream_t passed as void* (NULL = default stream);
+ *   - calls enqueue work on `stream` and return; no hidden synchronisation,
+ *     no allocation (workspaces are caller-provided);
+ *   - return value 0 = ok, < 0 = error (-(hipError_t) or DMDX_E_*);
+ *     dmdx_last_error() gives the message for the calling thread.
+ */
+#ifndef DMDX_H
+#define DMDX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DMDX_VERSION 100 /* 0.1.0 */
+
+#define DMDX_E_INVALID (-1000)  /* bad argument (shape, ld, null pointer)  */
+#define DMDX_E_WORKSPACE (-1001) /* workspace too small                      */
+#define DMDX_E_UNSUPPORTED (-1002)
+
+int dmdx_version(void);
+const char* dmdx_last_error(void);
+
+/* ---- K1: Gram matrix G = X^T X  (method of snapshots) ---------------------
+ * Takes over the O(m n^2) part of np.linalg.svd (era5_svd.py:251).
+ * X: m x n fp32 (ldx), G64: n x n fp64 (ldg), both triangles written.
+ * G32 (nullable): fp32 copy of G (ldg32).
+ * fp32 MFMA products, fp32 chains of at most 1024 rows, fp64 across chains.
+ * Deterministic (no atomics).  */
+size_t dmdx_syrk_workspace_bytes(int64_t m, int64_t n);
+int dmdx_syrk_f32(const float* X, int64_t m, int64_t n, int64_t ldx,
+                  double* G64, int64_t ldg, float* G32, int64_t ldg32,
+                  void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- K3: C = A^T B, A: K x na, B: K x nb (both K-contiguous) ---------------
+ * Z = X^T Y of the randomized range finder (extmath.py:351, `A.T @ Q`) and
+ * B = Q^T X (extmath.py:577).  C64: na x nb fp64 (ldc); C32 nullable.  */
+size_t dmdx_gemm_tn_workspace_bytes(int64_t K, int64_t na, int64_t nb);
+int dmdx_gemm_tn_f32(const float* A, int64_t lda, const float* B, int64_t ldb,
+                     int64_t K, int64_t na, int64_t nb,
+                     double* C64, int64_t ldc, float* C32, int64_t ldc32,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- K2: tall-skinny Y = X W -----------------------------------------------
+ * X: m x n (ldx, rows > ldx allowed), W: n x l (ldw), Y: m x l (ldy), l <= 256.
+ * U = X (V_r S^-1) of the method of snapshots and `A @ Q` of the range finder
+ * (extmath.py:349,355).  */
+int dmdx_gemm_nn_skinny_f32(const float* X, int64_t m, int64_t n, int64_t ldx,
+                            const float* W, int64_t ldw, int64_t l,
+                            float* Y, int64_t ldy, void* stream);
+
+/* ---- K5: per-row (space point) mean / std over time, centre, scale ---------
+ * slice_tools.py:171-179.  X: m x n (ldx) modified in place:
+ *   mean[i] = sum_j X[i,j] / n ; X[i,:] -= mean[i];
+ *   if (scale) { std[i] = sqrt(sum_j X[i,j]^2 / n) of the centred row (ddof 0);
+ *                X[i,:] /= std[i]; }
+ * mean: m floats (required), std: m floats (required iff scale).
+ * Sums are accumulated in fp64.  */
+int dmdx_row_center_scale_f32(float* X, int64_t m, int64_t n, int64_t ldx,
+                              float* mean, float* std, int scale, void* stream);
+
+/* ---- K6: Gram of the delay-embedded matrix from the plain Gram -------------
+ * Gd[i,j] = sum_{k<d} G[i+k, j+k], Gd is (n-d+1)^2  (slice_tools.py:207-211
+ * applied to X^T X).  fp64 in, fp64 out (Gd32 nullable fp32 copy).  */
+int dmdx_delay_shift_sum_f64(const double* G, int64_t n, int64_t ldg, int d,
+                             double* Gd, int64_t ldgd, float* Gd32, int64_t ldgd32,
+                             void* stream);
+
+/* ---- small helpers on the same stream --------------------------------------
+ * Y[:, j] *= alpha[j]  (m x l, ldy)  -- S^-1 scaling / sign flip of U columns */
+int dmdx_scale_columns_f32(float* Y, int64_t m, int64_t l, int64_t ldy,
+                           const float* alpha, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DMDX_H */

@@ -1,0 +1,44 @@
+"""CPU test double for the kernel provider of dmd_era5_amd.svd.
+
+TEST INFRASTRUCTURE: it lets the host-side algorithms (method of snapshots,
+randomized range finder, row-shard all-reduces over gloo) run in this GPU-less
+container.  It is never importable from the product package; the product's
+default provider (dmd_era5_amd.kernels.HipKernels) has no CPU path.
+Arithmetic: float64 accumulate on fp32 inputs, like the oracle would.
+"""
+import torch
+
+
+class CpuKernelDouble:
+    name = "cpu-double"
+
+    def syrk(self, Xt, want32=False):
+        X = Xt.to(torch.float64)
+        G = X @ X.T
+        return (G, G.float()) if want32 else G
+
+    def gemm_tn(self, At, Bt, want32=False):
+        C = Bt.to(torch.float64) @ At.to(torch.float64).T
+        return (C, C.float()) if want32 else C
+
+    def skinny(self, Xt, Wt):
+        return (Wt.to(torch.float64) @ Xt.to(torch.float64)).float()
+
+    def row_center_scale_(self, Xt, scale):
+        mean = Xt.to(torch.float64).mean(dim=0).float()
+        Xt -= mean
+        std = None
+        if scale:
+            std = Xt.to(torch.float64).std(dim=0, unbiased=False).float()
+            Xt /= std
+        return mean, std
+
+    def delay_shift_sum(self, G, d, want32=False):
+        n = G.shape[0]
+        nd = n - d + 1
+        Gd = sum(G[k:k + nd, k:k + nd] for k in range(d)).contiguous()
+        return (Gd, Gd.float()) if want32 else Gd
+
+    def scale_columns_(self, Yt, alpha):
+        Yt *= alpha[:, None]
+        return Yt

@@ -13,7 +13,7 @@
 //   MFMAs: lane (r, h) reads k = 8t+4h .. 8t+4h+3 of its row, MFMA j uses
 //   element j of both operands -- the same k permutation on both sides, so
 //   the contraction is unchanged.
-//   Numerics: fp32 MFMA chains of at most FLUSH_CHUNKS*32 = 1024 rows, then the
+//   Numerics: fp32 MFMA chains of at most 32 chunks * 32 = 1024 rows, then the
 //   chain is added in fp64 into the unit's own partial tile in HBM (owned
 //   read-modify-write, no atomics => deterministic); a second kernel sums the
 //   K-splits in fp64 and writes D (both triangles in SYRK mode).
@@ -33,7 +33,7 @@ constexpr int BT = 128;            // output tile edge
 constexpr int BK = 32;             // K rows per stage
 constexpr int LDT = BK + 4;        // padded LDS row (floats)
 constexpr int NTH = 256;
-constexpr int FLUSH_CHUNKS = 32;   // fp32 chain length = 32*32 = 1024 rows
+// fp32 chain length = 32 chunks * 32 rows = 1024 rows (hard-wired in the fold schedule)
 constexpr int TILE_ELEMS = BT * BT;
 
 struct TnParams {
@@ -91,18 +91,19 @@ __device__ inline void decode_tile(const TnParams& p, int t, int& ta, int& tb) {
   }
 }
 
+// full chunk: no guards at all (columns are clamped to valid ones by the caller)
 template <bool ALIGNED>
-__device__ inline f32x4 load4(const float* p, bool valid, int64_t k, int64_t kend) {
+__device__ inline f32x4 load4_full(const float* p) {
+  if (ALIGNED) return *reinterpret_cast<const f32x4*>(p);
+  f32x4 v = {p[0], p[1], p[2], p[3]};
+  return v;
+}
+// K tail (last chunk of the last split only): rows >= kend read as zero
+__device__ inline f32x4 load4_tail(const float* p, int64_t k, int64_t kend) {
   f32x4 v = {0.f, 0.f, 0.f, 0.f};
-  if (valid) {
-    if (ALIGNED && k + 4 <= kend) {
-      v = *reinterpret_cast<const f32x4*>(p + k);
-    } else {
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if (k + e < kend) v[e] = p[k + e];
-    }
-  }
+  for (int e = 0; e < 4; ++e)
+    if (k + e < kend) v[e] = p[e];
   return v;
 }
 
@@ -129,6 +130,8 @@ __global__ __launch_bounds__(NTH, 2) void gemm_tn_partial_kernel(TnParams p) {
   if (c_end > p.chunks_total) c_end = p.chunks_total;
   const int nchunks = c_end - c_begin;
   const int64_t kend = p.K;
+  // index of the one chunk that may be partial (K % 32 != 0), else -1
+  const int tail_chunk = (kend % BK) ? p.chunks_total - 1 : -1;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -136,20 +139,21 @@ __global__ __launch_bounds__(NTH, 2) void gemm_tn_partial_kernel(TnParams p) {
   const int wr = wave >> 1, wc = wave & 1;
   const int l31 = lane & 31, lh = lane >> 5;
 
-  // ---- staging assignment: 4 x 16-byte pieces per operand per thread ----
+  // ---- staging assignment: 4 x 16-byte pieces per operand per thread.
+  // Columns past the matrix edge are clamped onto the last valid column: they
+  // only feed rows/columns of D that the reduce kernel never stores.
   const int scol = tid >> 3;  // + 32*i
   const int sq = tid & 7;     // k offset 4*sq
   const float* aptr[4];
   const float* bptr[4];
-  bool aval[4], bval[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     int ca = row0 + scol + 32 * i;
     int cb = col0 + scol + 32 * i;
-    aval[i] = ca < p.nrow;
-    bval[i] = cb < p.ncol;
-    aptr[i] = p.A + (int64_t)(aval[i] ? ca : 0) * p.lda + 4 * sq;
-    bptr[i] = p.B + (int64_t)(bval[i] ? cb : 0) * p.ldb + 4 * sq;
+    ca = ca < p.nrow ? ca : p.nrow - 1;
+    cb = cb < p.ncol ? cb : p.ncol - 1;
+    aptr[i] = p.A + (int64_t)ca * p.lda + 4 * sq;
+    bptr[i] = p.B + (int64_t)cb * p.ldb + 4 * sq;
   }
   const int sts = (scol * LDT + 4 * sq);  // + 32*i*LDT
 
@@ -161,42 +165,57 @@ __global__ __launch_bounds__(NTH, 2) void gemm_tn_partial_kernel(TnParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
+  // ---- fp64 partial tile of this unit (owned: only this workgroup touches it).
+  // Block q = (mi, ni) of the wave is folded into it every 32 chunks, the four
+  // blocks staggered by 8 chunks so that at most one block's 16 old values are
+  // in flight at a time (prefetched one chunk ahead of the fold).
   double* Pt = p.P + ((size_t)split * p.ntiles + tile) * TILE_ELEMS;
-  bool first_flush = true;
-
-  auto flush = [&]() {
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          int i = 64 * wr + 32 * mi + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          int j = 64 * wc + 32 * ni + l31;
-          double* q = Pt + i * BT + j;
-          double v = (double)acc[mi][ni][r];
-          if (!first_flush) v += *q;
-          *q = v;
-          acc[mi][ni][r] = 0.f;
-        }
-    first_flush = false;
-  };
+  const int lane_off = (64 * wr + 4 * lh) * BT + 64 * wc + l31;
+  double oldv[16];
+#define DMDX_BLOCK_OFF(mi, ni, r) ((32 * (mi) + ((r) & 3) + 8 * ((r) >> 2)) * BT + 32 * (ni))
+#define DMDX_PREFETCH(mi, ni)                                                     \
+  do {                                                                            \
+    int lo_ = lane_off;                                                           \
+    asm volatile("" : "+v"(lo_)); /* keep the 16 addresses out of loop-invariant hoisting */ \
+    const double* q_ = Pt + lo_;                                                  \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r) oldv[r] = q_[DMDX_BLOCK_OFF(mi, ni, r)]; \
+  } while (0)
+#define DMDX_COMMIT(mi, ni, have_old)                                             \
+  do {                                                                            \
+    int lo_ = lane_off;                                                           \
+    asm volatile("" : "+v"(lo_));                                                 \
+    double* q_ = Pt + lo_;                                                        \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r) {                              \
+      double v_ = (double)acc[mi][ni][r];                                         \
+      if (have_old) v_ += oldv[r];                                                \
+      q_[DMDX_BLOCK_OFF(mi, ni, r)] = v_;                                         \
+      acc[mi][ni][r] = 0.f;                                                       \
+    }                                                                             \
+  } while (0)
 
   if (nchunks <= 0) {  // empty split: the partial tile must still be defined
-    flush();
+    DMDX_COMMIT(0, 0, false);
+    DMDX_COMMIT(0, 1, false);
+    DMDX_COMMIT(1, 0, false);
+    DMDX_COMMIT(1, 1, false);
     return;
   }
 
   f32x4 ra[4], rb[4];
-  // aptr/bptr already include the +4*sq offset, so indices and the K bound
-  // handed to load4 are relative to them.
   auto load_stage = [&](int chunk) {
-    int64_t k0 = (int64_t)chunk * BK;
-    int64_t krel_end = kend - 4 * sq;  // bound for indices relative to aptr/bptr
+    const int64_t k0 = (int64_t)chunk * BK;
+    if (chunk != tail_chunk) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      ra[i] = load4<ALIGNED>(aptr[i], aval[i], k0, krel_end);
-      rb[i] = load4<ALIGNED>(bptr[i], bval[i], k0, krel_end);
+      for (int i = 0; i < 4; ++i) {
+        ra[i] = load4_full<ALIGNED>(aptr[i] + k0);
+        rb[i] = load4_full<ALIGNED>(bptr[i] + k0);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        ra[i] = load4_tail(aptr[i] + k0, k0 + 4 * sq, kend);
+        rb[i] = load4_tail(bptr[i] + k0, k0 + 4 * sq, kend);
+      }
     }
   };
   auto store_stage = [&](int st) {
@@ -209,42 +228,96 @@ __global__ __launch_bounds__(NTH, 2) void gemm_tn_partial_kernel(TnParams p) {
     }
   };
 
+  // MFMA operand fragments, two register sets: the set for k-step t+1 is read
+  // from LDS while the 16 MFMAs of k-step t run.
+  f32x4 fa0[2], fb0[2], fa1[2], fb1[2];
+  const int frag_a = (64 * wr + l31) * LDT + 4 * lh;
+  const int frag_b = (64 * wc + l31) * LDT + 4 * lh;
+#define DMDX_READ_FRAGS(FA, FB, st, t)                                               \
+  do {                                                                               \
+    const float* as_ = As + (st) * BT * LDT + frag_a + 8 * (t);                      \
+    const float* bs_ = Bs + (st) * BT * LDT + frag_b + 8 * (t);                      \
+    FA[0] = *reinterpret_cast<const f32x4*>(as_);                                    \
+    FA[1] = *reinterpret_cast<const f32x4*>(as_ + 32 * LDT);                         \
+    FB[0] = *reinterpret_cast<const f32x4*>(bs_);                                    \
+    FB[1] = *reinterpret_cast<const f32x4*>(bs_ + 32 * LDT);                         \
+  } while (0)
+#define DMDX_MFMA16(FA, FB)                                                                   \
+  do {                                                                                        \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                           \
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[0][j], FB[0][j], acc[0][0], 0, 0, 0); \
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[0][j], FB[1][j], acc[0][1], 0, 0, 0); \
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[1][j], FB[0][j], acc[1][0], 0, 0, 0); \
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[1][j], FB[1][j], acc[1][1], 0, 0, 0); \
+    }                                                                                         \
+  } while (0)
+
   load_stage(c_begin);
   store_stage(0);
   __syncthreads();
+  DMDX_READ_FRAGS(fa0, fb0, 0, 0);
 
   int cur = 0;
-  int since_flush = 0;
   for (int c = 0; c < nchunks; ++c) {
     const bool has_next = (c + 1 < nchunks);
     if (has_next) load_stage(c_begin + c + 1);
-
-    const float* as = As + cur * BT * LDT + (64 * wr + l31) * LDT + 4 * lh;
-    const float* bs = Bs + cur * BT * LDT + (64 * wc + l31) * LDT + 4 * lh;
-#pragma unroll
-    for (int t = 0; t < BK / 8; ++t) {
-      f32x4 a0 = *reinterpret_cast<const f32x4*>(as + 8 * t);
-      f32x4 a1 = *reinterpret_cast<const f32x4*>(as + 32 * LDT + 8 * t);
-      f32x4 b0 = *reinterpret_cast<const f32x4*>(bs + 8 * t);
-      f32x4 b1 = *reinterpret_cast<const f32x4*>(bs + 32 * LDT + 8 * t);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b0[j], acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b1[j], acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b0[j], acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b1[j], acc[1][1], 0, 0, 0);
+    const int phase = c & 7, fq = (c >> 3) & 3;
+    if (phase == 6 && c >= 32) {  // old partial values of block fq, used one chunk later
+      switch (fq) {
+        case 0: DMDX_PREFETCH(0, 0); break;
+        case 1: DMDX_PREFETCH(0, 1); break;
+        case 2: DMDX_PREFETCH(1, 0); break;
+        default: DMDX_PREFETCH(1, 1); break;
       }
     }
+
+    DMDX_READ_FRAGS(fa1, fb1, cur, 1);
+    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);   // 4 ds_read
+    DMDX_MFMA16(fa0, fb0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);  // 16 mfma
+    DMDX_READ_FRAGS(fa0, fb0, cur, 2);
+    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+    DMDX_MFMA16(fa1, fb1);
+    __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+    DMDX_READ_FRAGS(fa1, fb1, cur, 3);
+    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+    DMDX_MFMA16(fa0, fb0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+    DMDX_MFMA16(fa1, fb1);
 
     if (has_next) store_stage(cur ^ 1);
     __syncthreads();
     cur ^= 1;
-    if (++since_flush == FLUSH_CHUNKS) {
-      flush();
-      since_flush = 0;
+    if (has_next) DMDX_READ_FRAGS(fa0, fb0, cur, 0);
+    if (phase == 7) {
+      if (c >= 32) {
+        switch (fq) {
+          case 0: DMDX_COMMIT(0, 0, true); break;
+          case 1: DMDX_COMMIT(0, 1, true); break;
+          case 2: DMDX_COMMIT(1, 0, true); break;
+          default: DMDX_COMMIT(1, 1, true); break;
+        }
+      } else {
+        switch (fq) {
+          case 0: DMDX_COMMIT(0, 0, false); break;
+          case 1: DMDX_COMMIT(0, 1, false); break;
+          case 2: DMDX_COMMIT(1, 0, false); break;
+          default: DMDX_COMMIT(1, 1, false); break;
+        }
+      }
     }
   }
-  if (since_flush > 0 || first_flush) flush();
+  // final fold of whatever each block still holds (block q was folded before iff
+  // the unit ran at least 8q+8 chunks)
+  if (nchunks >= 8) { DMDX_PREFETCH(0, 0); DMDX_COMMIT(0, 0, true); } else { DMDX_COMMIT(0, 0, false); }
+  if (nchunks >= 16) { DMDX_PREFETCH(0, 1); DMDX_COMMIT(0, 1, true); } else { DMDX_COMMIT(0, 1, false); }
+  if (nchunks >= 24) { DMDX_PREFETCH(1, 0); DMDX_COMMIT(1, 0, true); } else { DMDX_COMMIT(1, 0, false); }
+  if (nchunks >= 32) { DMDX_PREFETCH(1, 1); DMDX_COMMIT(1, 1, true); } else { DMDX_COMMIT(1, 1, false); }
+#undef DMDX_READ_FRAGS
+#undef DMDX_MFMA16
+#undef DMDX_PREFETCH
+#undef DMDX_COMMIT
+#undef DMDX_BLOCK_OFF
 }
 
 // Sum the K-splits in fp64 and scatter the tile into D (row-major view:
@@ -254,7 +327,9 @@ __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(
     const double* P, int nsplit, int ntiles, int ntr, int ntc, int syrk, int nrow, int ncol,
     double* D64, int64_t ld64, float* D32, int64_t ld32) {
   __shared__ double tr[32][33];
-  const int tile = blockIdx.x;
+  // one workgroup per (tile, 32x32 sub-block)
+  const int tile = blockIdx.x >> 4;
+  const int sb = blockIdx.x & 15;
   int ta, tb;
   if (syrk) {
     decode_tri(tile, ntr, ta, tb);
@@ -270,42 +345,41 @@ __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(
   const int row0 = ta * BT, col0 = tb * BT;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
   const bool diag = syrk && (ta == tb);
-  for (int sb = 0; sb < 16; ++sb) {
-    const int si = (sb >> 2) * 32, sj = (sb & 3) * 32;
-    if (diag && si > sj) continue;  // lower sub-blocks of a diagonal tile: mirrored from upper
-    double v[4];
+  const int si = (sb >> 2) * 32, sj = (sb & 3) * 32;
+  if (diag && si > sj) return;  // lower sub-blocks of a diagonal tile: mirrored from the upper ones
+  if (row0 + si >= nrow || col0 + sj >= ncol) return;
+  double v[4] = {0.0, 0.0, 0.0, 0.0};
+  const double* src = P + (size_t)tile * TILE_ELEMS + (si + ty) * BT + sj + tx;
+  for (int sp = 0; sp < nsplit; ++sp) {
+    const double* q = src + (size_t)sp * ntiles * TILE_ELEMS;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      int i = si + ty + 8 * q, j = sj + tx;
-      double s = 0.0;
-      for (int sp = 0; sp < nsplit; ++sp)
-        s += P[((size_t)sp * ntiles + tile) * TILE_ELEMS + i * BT + j];
-      v[q] = s;
-      int gi = row0 + i, gj = col0 + j;
-      bool keep = !(diag && i > j);
+    for (int k = 0; k < 4; ++k) v[k] += q[8 * k * BT];
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int i = si + ty + 8 * k, j = sj + tx;
+    const int gi = row0 + i, gj = col0 + j;
+    const bool keep = !(diag && i > j);
+    if (keep && gi < nrow && gj < ncol) {
+      D64[(int64_t)gi * ld64 + gj] = v[k];
+      if (D32) D32[(int64_t)gi * ld32 + gj] = (float)v[k];
+    }
+    tr[ty + 8 * k][tx] = v[k];
+  }
+  if (syrk) {
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      // mirrored element: source (i = si+tx, j = sj+ty+8k) -> D[gj][gi]
+      const int i = si + tx, j = sj + ty + 8 * k;
+      const double s = tr[tx][ty + 8 * k];
+      const int gi = row0 + i, gj = col0 + j;
+      const bool keep = !(diag && i >= j);
       if (keep && gi < nrow && gj < ncol) {
-        D64[(int64_t)gi * ld64 + gj] = s;
-        if (D32) D32[(int64_t)gi * ld32 + gj] = (float)s;
+        D64[(int64_t)gj * ld64 + gi] = s;
+        if (D32) D32[(int64_t)gj * ld32 + gi] = (float)s;
       }
-      tr[ty + 8 * q][tx] = s;
     }
-    if (syrk) {
-      __syncthreads();
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        // mirrored element: source (i = si+tx, j = sj+ty+8q) -> D[gj][gi]
-        int i = si + tx, j = sj + ty + 8 * q;
-        double s = tr[tx][ty + 8 * q];
-        int gi = row0 + i, gj = col0 + j;
-        bool keep = !(diag && i >= j);
-        if (keep && gi < nrow && gj < ncol) {
-          D64[(int64_t)gj * ld64 + gi] = s;
-          if (D32) D32[(int64_t)gj * ld32 + gi] = (float)s;
-        }
-      }
-      __syncthreads();
-    }
-    (void)v;
   }
 }
 
@@ -327,7 +401,7 @@ Plan make_plan(int64_t K, int64_t nrow, int64_t ncol, int syrk) {
   if (maxs < 1) maxs = 1;
   if (want > maxs) want = maxs;
   if (want < 1) want = 1;
-  if (want > 1024) want = 1024;
+  if (want > 256) want = 256;
   pl.chunks_per_split = (int)((pl.chunks_total + want - 1) / want);
   pl.nsplit = (pl.chunks_total + pl.chunks_per_split - 1) / pl.chunks_per_split;
   pl.ws_bytes = (size_t)pl.nsplit * pl.ntiles * TILE_ELEMS * sizeof(double);
@@ -356,7 +430,7 @@ int run_tn(const float* A, int64_t lda, const float* B, int64_t ldb, int64_t K, 
   else
     hipLaunchKernelGGL(gemm_tn_partial_kernel<false>, grid, dim3(NTH), 0, stream, p);
   DMDX_LAUNCH_CHECK();
-  hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3(pl.ntiles), dim3(256), 0, stream, p.P, pl.nsplit,
+  hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3(pl.ntiles * 16), dim3(256), 0, stream, p.P, pl.nsplit,
                      pl.ntiles, pl.ntr, pl.ntc, syrk, (int)nrow, (int)ncol, D64, ld64, D32, ld32);
   DMDX_LAUNCH_CHECK();
   return 0;

@@ -1,0 +1,20 @@
+"""Scratch micro-benchmark of the Gram kernel (K1) alone: TFLOP/s vs the fp32 MFMA peak."""
+import argparse, sys, os, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dmd_era5_amd.kernels import default_kernels
+ap = argparse.ArgumentParser()
+ap.add_argument("--m", type=int, default=262144)
+ap.add_argument("--n", type=int, default=8760)
+ap.add_argument("--reps", type=int, default=3)
+a = ap.parse_args()
+K = default_kernels()
+g = torch.Generator(device="cuda").manual_seed(1)
+Xt = torch.randn((a.n, a.m), generator=g, device="cuda", dtype=torch.float32)
+G = K.syrk(Xt); torch.cuda.synchronize()
+K.events = []
+for _ in range(a.reps): G = K.syrk(Xt)
+torch.cuda.synchronize()
+ms = [e0.elapsed_time(e1) for _, _, e0, e1 in K.events]
+fl = a.m * a.n * (a.n + 1)
+print(f"syrk m={a.m} n={a.n}: {min(ms):.2f} ms best, {sum(ms)/len(ms):.2f} avg -> {fl/min(ms)/1e9:.1f} TFLOP/s best ({fl/min(ms)/1e9/157.3*100:.1f}% of 157.3)", flush=True)

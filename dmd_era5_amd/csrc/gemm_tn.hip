@@ -24,6 +24,7 @@
 // the 32 blocks that land on one XCD (blockIdx % 8 equal) take one patch.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "dmdx_common.h"
 
@@ -31,7 +32,7 @@ namespace {
 
 constexpr int BT = 128;            // output tile edge
 constexpr int BK = 32;             // K rows per stage
-constexpr int LDT = BK + 4;        // padded LDS row (floats)
+constexpr int FOLD = 128;          // chunks per fp32 chain (128 * 32 = 4096 rows) before the fp64 fold
 constexpr int NTH = 256;
 // fp32 chain length = 32 chunks * 32 rows = 1024 rows (hard-wired in the fold schedule)
 constexpr int TILE_ELEMS = BT * BT;
@@ -53,17 +54,18 @@ struct TnParams {
 
 // upper-triangle tile enumeration: super-rows of 4 tile rows, column-major
 // inside a super-row (see header comment).
+constexpr int SR = 8;  // tile rows per super-row: 64 consecutive tiles ~ an 8x8 patch
 __device__ __host__ inline void decode_tri(int t, int nt, int& ta, int& tb) {
   int r0 = 0;
   for (;;) {
-    int nrows = nt - r0 < 4 ? nt - r0 : 4;
+    int nrows = nt - r0 < SR ? nt - r0 : SR;
     int ncols = nt - r0;
     int cnt = nrows * (nrows + 1) / 2 + (ncols - nrows) * nrows;
     if (t < cnt) break;
     t -= cnt;
-    r0 += 4;
+    r0 += SR;
   }
-  int nrows = nt - r0 < 4 ? nt - r0 : 4;
+  int nrows = nt - r0 < SR ? nt - r0 : SR;
   int head = nrows * (nrows + 1) / 2;
   if (t < head) {
     int c = 0;
@@ -80,24 +82,24 @@ __device__ __host__ inline void decode_tri(int t, int nt, int& ta, int& tb) {
 __device__ inline void decode_tile(const TnParams& p, int t, int& ta, int& tb) {
   if (p.syrk) {
     decode_tri(t, p.ntr, ta, tb);
-  } else {  // 4-row super-rows, column-major inside (same patch idea)
-    int per_sr = 4 * p.ntc;
+  } else {  // SR-row super-rows, column-major inside (same patch idea)
+    int per_sr = SR * p.ntc;
     int sr = t / per_sr;
-    int r0 = sr * 4;
-    int nrows = p.ntr - r0 < 4 ? p.ntr - r0 : 4;
+    int r0 = sr * SR;
+    int nrows = p.ntr - r0 < SR ? p.ntr - r0 : SR;
     int tt = t - sr * per_sr;
     tb = tt / nrows;
     ta = r0 + tt % nrows;
   }
 }
 
-// full chunk: no guards at all (columns are clamped to valid ones by the caller)
-template <bool ALIGNED>
-__device__ inline f32x4 load4_full(const float* p) {
-  if (ALIGNED) return *reinterpret_cast<const f32x4*>(p);
-  f32x4 v = {p[0], p[1], p[2], p[3]};
-  return v;
-}
+// LDS image of one operand stage: [128 columns][32 k] floats, 128 B per column and NOT
+// padded (an LDS-DMA wave-instruction writes 1 KiB linearly = 8 columns).  Bank
+// conflicts of the ds_read_b128 fragment reads are removed by an XOR swizzle of the
+// 16-byte k-chunk index with f(col) = (col >> 1) & 7, applied on the SOURCE address of
+// the DMA (and on the register-staged tail path) and on the read address.
+__device__ __forceinline__ int swz(int col) { return (col >> 1) & 7; }
+
 // K tail (last chunk of the last split only): rows >= kend read as zero
 __device__ inline f32x4 load4_tail(const float* p, int64_t k, int64_t kend) {
   f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -107,17 +109,25 @@ __device__ inline f32x4 load4_tail(const float* p, int64_t k, int64_t kend) {
   return v;
 }
 
-template <bool ALIGNED>
+#define DMDX_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define DMDX_GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+
+// DMA = true : global -> LDS by global_load_lds_dwordx4 (needs 16-byte aligned
+//              bases and leading dimensions); the K-tail chunk goes through registers.
+// DMA = false: everything register-staged with scalar loads (any alignment).
+// ABL: timing-only ablations for diagnosis (results are wrong when ABL != 0):
+//   1 no global->LDS staging, 2 no barrier, 4 all units stream the same panel, 8 no fp64 fold.  Selected by DMDX_TN_ABLATE.
+template <bool DMA, int ABL = 0>
 __global__ __launch_bounds__(NTH, 2) void gemm_tn_partial_kernel(TnParams p) {
-  __shared__ __attribute__((aligned(16))) float lds[2 * 2 * BT * LDT];
-  float* As = lds;                 // [2][BT][LDT]
-  float* Bs = lds + 2 * BT * LDT;  // [2][BT][LDT]
+  __shared__ __attribute__((aligned(16))) float lds[2 * 2 * BT * BK];
+  // stage st, operand o (0 = A, 1 = B): lds + (st * 2 + o) * BT * BK
+  constexpr int OPSZ = BT * BK;  // floats per operand stage (16 KB)
 
   // ---- unit decode (XCD-aware) ----
   const int total = gridDim.x;
   int b = blockIdx.x;
-  int g = b >> 8;
-  int pos = ((g << 8) + 256 <= total) ? (g << 8) + (b & 7) * 32 + ((b & 255) >> 3) : b;
+  int g = b >> 9;  // groups of 512 blocks: the 64 that land on one XCD (b % 8) take 64 consecutive units
+  int pos = ((g << 9) + 512 <= total) ? (g << 9) + (b & 7) * 64 + ((b & 511) >> 3) : b;
   const int split = pos / p.ntiles;
   const int tile = pos - split * p.ntiles;
   int ta, tb;
@@ -135,27 +145,31 @@ __global__ __launch_bounds__(NTH, 2) void gemm_tn_partial_kernel(TnParams p) {
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 1, wc = wave & 1;
   const int l31 = lane & 31, lh = lane >> 5;
 
-  // ---- staging assignment: 4 x 16-byte pieces per operand per thread.
-  // Columns past the matrix edge are clamped onto the last valid column: they
-  // only feed rows/columns of D that the reduce kernel never stores.
-  const int scol = tid >> 3;  // + 32*i
-  const int sq = tid & 7;     // k offset 4*sq
+  // ---- staging assignment.  Columns past the matrix edge are clamped onto the last
+  // valid column: they only feed rows/columns of D that the reduce kernel never stores.
+  // DMA: wave w, instruction i (0..3) fills columns 32w + 8i + (lane >> 3), the lane's
+  // 16-byte slot (lane & 7) holds global k-chunk (lane & 7) ^ swz(col).
+  // Register path: thread -> column (tid >> 3) + 32 i, k-chunk (tid & 7).
   const float* aptr[4];
   const float* bptr[4];
+  int sts[4];  // register path: float offset inside an operand stage
+  int kq[4];   // 4 * (global k-chunk of this piece)
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    int ca = row0 + scol + 32 * i;
-    int cb = col0 + scol + 32 * i;
+    const int lc = DMA ? 32 * wave + 8 * i + (lane >> 3) : (tid >> 3) + 32 * i;  // local column
+    const int q = DMA ? ((lane & 7) ^ swz(lc)) : (tid & 7);                       // global k-chunk
+    int ca = (ABL & 4) ? lc : row0 + lc, cb = (ABL & 4) ? lc : col0 + lc;  // ABL 4: every unit streams panel 0
     ca = ca < p.nrow ? ca : p.nrow - 1;
     cb = cb < p.ncol ? cb : p.ncol - 1;
-    aptr[i] = p.A + (int64_t)ca * p.lda + 4 * sq;
-    bptr[i] = p.B + (int64_t)cb * p.ldb + 4 * sq;
+    aptr[i] = p.A + (int64_t)ca * p.lda + 4 * q;
+    bptr[i] = p.B + (int64_t)cb * p.ldb + 4 * q;
+    sts[i] = lc * BK + 4 * (DMA ? (lane & 7) : ((tid & 7) ^ swz(lc)));
+    kq[i] = 4 * q;
   }
-  const int sts = (scol * LDT + 4 * sq);  // + 32*i*LDT
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -166,9 +180,10 @@ __global__ __launch_bounds__(NTH, 2) void gemm_tn_partial_kernel(TnParams p) {
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
   // ---- fp64 partial tile of this unit (owned: only this workgroup touches it).
-  // Block q = (mi, ni) of the wave is folded into it every 32 chunks, the four
-  // blocks staggered by 8 chunks so that at most one block's 16 old values are
-  // in flight at a time (prefetched one chunk ahead of the fold).
+  // Block q = (mi, ni) of the wave is folded into it every FOLD chunks (fp32 chains of
+  // FOLD*32 rows), the four blocks staggered by FOLD/4 chunks so that at most one
+  // block's 16 old values are in flight (prefetched one chunk ahead of the fold).
+  // The partial tile is streamed (non-temporal): it is touched once per FOLD chunks.
   double* Pt = p.P + ((size_t)split * p.ntiles + tile) * TILE_ELEMS;
   const int lane_off = (64 * wr + 4 * lh) * BT + 64 * wc + l31;
   double oldv[16];
@@ -178,7 +193,8 @@ __global__ __launch_bounds__(NTH, 2) void gemm_tn_partial_kernel(TnParams p) {
     int lo_ = lane_off;                                                           \
     asm volatile("" : "+v"(lo_)); /* keep the 16 addresses out of loop-invariant hoisting */ \
     const double* q_ = Pt + lo_;                                                  \
-    _Pragma("unroll") for (int r = 0; r < 16; ++r) oldv[r] = q_[DMDX_BLOCK_OFF(mi, ni, r)]; \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r)                                \
+        oldv[r] = __builtin_nontemporal_load(q_ + DMDX_BLOCK_OFF(mi, ni, r));     \
   } while (0)
 #define DMDX_COMMIT(mi, ni, have_old)                                             \
   do {                                                                            \
@@ -188,7 +204,7 @@ __global__ __launch_bounds__(NTH, 2) void gemm_tn_partial_kernel(TnParams p) {
     _Pragma("unroll") for (int r = 0; r < 16; ++r) {                              \
       double v_ = (double)acc[mi][ni][r];                                         \
       if (have_old) v_ += oldv[r];                                                \
-      q_[DMDX_BLOCK_OFF(mi, ni, r)] = v_;                                         \
+      __builtin_nontemporal_store(v_, q_ + DMDX_BLOCK_OFF(mi, ni, r));            \
       acc[mi][ni][r] = 0.f;                                                       \
     }                                                                             \
   } while (0)
@@ -201,46 +217,65 @@ __global__ __launch_bounds__(NTH, 2) void gemm_tn_partial_kernel(TnParams p) {
     return;
   }
 
-  f32x4 ra[4], rb[4];
-  auto load_stage = [&](int chunk) {
+  // ---- global -> LDS for one chunk into stage st
+  auto stage_regs = [&](int chunk, int st, bool tail) {  // register path (tail / unaligned)
     const int64_t k0 = (int64_t)chunk * BK;
-    if (chunk != tail_chunk) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        ra[i] = load4_full<ALIGNED>(aptr[i] + k0);
-        rb[i] = load4_full<ALIGNED>(bptr[i] + k0);
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        ra[i] = load4_tail(aptr[i] + k0, k0 + 4 * sq, kend);
-        rb[i] = load4_tail(bptr[i] + k0, k0 + 4 * sq, kend);
-      }
-    }
-  };
-  auto store_stage = [&](int st) {
-    float* as = As + st * BT * LDT + sts;
-    float* bs = Bs + st * BT * LDT + sts;
+    f32x4 ra[4], rb[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      *reinterpret_cast<f32x4*>(as + 32 * i * LDT) = ra[i];
-      *reinterpret_cast<f32x4*>(bs + 32 * i * LDT) = rb[i];
+      if (tail) {
+        ra[i] = load4_tail(aptr[i] + k0, k0 + kq[i], kend);
+        rb[i] = load4_tail(bptr[i] + k0, k0 + kq[i], kend);
+      } else {
+        const float* pa = aptr[i] + k0;
+        const float* pb = bptr[i] + k0;
+        ra[i] = f32x4{pa[0], pa[1], pa[2], pa[3]};
+        rb[i] = f32x4{pb[0], pb[1], pb[2], pb[3]};
+      }
+    }
+    float* as = lds + (st * 2 + 0) * OPSZ;
+    float* bs = lds + (st * 2 + 1) * OPSZ;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *reinterpret_cast<f32x4*>(as + sts[i]) = ra[i];
+      *reinterpret_cast<f32x4*>(bs + sts[i]) = rb[i];
+    }
+  };
+  auto stage_dma = [&](int chunk, int st) {
+    const int64_t k0 = (int64_t)chunk * BK;
+    float* as = lds + (st * 2 + 0) * OPSZ + (32 * wave) * BK;
+    float* bs = lds + (st * 2 + 1) * OPSZ + (32 * wave) * BK;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_global_load_lds(DMDX_GLB_PTR(aptr[i] + k0), DMDX_LDS_PTR(as + 8 * i * BK), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(DMDX_GLB_PTR(bptr[i] + k0), DMDX_LDS_PTR(bs + 8 * i * BK), 16, 0, 0);
+    }
+  };
+  auto stage = [&](int chunk, int st) {
+    if (DMA) {
+      if (chunk != tail_chunk) stage_dma(chunk, st);
+      else stage_regs(chunk, st, true);
+    } else {
+      stage_regs(chunk, st, chunk == tail_chunk);
     }
   };
 
-  // MFMA operand fragments, two register sets: the set for k-step t+1 is read
-  // from LDS while the 16 MFMAs of k-step t run.
+  // ---- MFMA operand fragments, two register sets: the set for k-step t+1 is read from
+  // LDS while the 16 MFMAs of k-step t run.  Lane (r = lane&31, h = lane>>5) reads, for
+  // k-step t, the 16-byte k-chunk (2t + h) of its column, stored at slot (2t+h) ^ swz.
   f32x4 fa0[2], fb0[2], fa1[2], fb1[2];
-  const int frag_a = (64 * wr + l31) * LDT + 4 * lh;
-  const int frag_b = (64 * wc + l31) * LDT + 4 * lh;
+  int foff[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) foff[t] = l31 * BK + 4 * ((2 * t + lh) ^ swz(l31));
+  const int frag_a = 64 * wr * BK, frag_b = 64 * wc * BK;
 #define DMDX_READ_FRAGS(FA, FB, st, t)                                               \
   do {                                                                               \
-    const float* as_ = As + (st) * BT * LDT + frag_a + 8 * (t);                      \
-    const float* bs_ = Bs + (st) * BT * LDT + frag_b + 8 * (t);                      \
+    const float* as_ = lds + ((st) * 2 + 0) * OPSZ + frag_a + foff[t];               \
+    const float* bs_ = lds + ((st) * 2 + 1) * OPSZ + frag_b + foff[t];               \
     FA[0] = *reinterpret_cast<const f32x4*>(as_);                                    \
-    FA[1] = *reinterpret_cast<const f32x4*>(as_ + 32 * LDT);                         \
+    FA[1] = *reinterpret_cast<const f32x4*>(as_ + 32 * BK);                          \
     FB[0] = *reinterpret_cast<const f32x4*>(bs_);                                    \
-    FB[1] = *reinterpret_cast<const f32x4*>(bs_ + 32 * LDT);                         \
+    FB[1] = *reinterpret_cast<const f32x4*>(bs_ + 32 * BK);                          \
   } while (0)
 #define DMDX_MFMA16(FA, FB)                                                                   \
   do {                                                                                        \
@@ -252,17 +287,47 @@ __global__ __launch_bounds__(NTH, 2) void gemm_tn_partial_kernel(TnParams p) {
     }                                                                                         \
   } while (0)
 
-  load_stage(c_begin);
-  store_stage(0);
+  stage(c_begin, 0);
   __syncthreads();
   DMDX_READ_FRAGS(fa0, fb0, 0, 0);
 
+  // DMA pair i = pieces i of A and B of the next chunk.  (Issuing the pairs between the
+  // MFMAs of the k-steps instead of up front measured 1-2 % slower.)
+#define DMDX_DMA_PAIR(i)                                                                          \
+  do {                                                                                            \
+    if (dma_next) {                                                                               \
+      __builtin_amdgcn_global_load_lds(DMDX_GLB_PTR(aptr[i] + knext),                             \
+                                       DMDX_LDS_PTR(dma_as + 8 * (i) * BK), 16, 0, 0);            \
+      __builtin_amdgcn_global_load_lds(DMDX_GLB_PTR(bptr[i] + knext),                             \
+                                       DMDX_LDS_PTR(dma_bs + 8 * (i) * BK), 16, 0, 0);            \
+    }                                                                                             \
+  } while (0)
+#define DMDX_MFMA4(FA, FB, j)                                                                   \
+  do {                                                                                          \
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[0][j], FB[0][j], acc[0][0], 0, 0, 0);   \
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[0][j], FB[1][j], acc[0][1], 0, 0, 0);   \
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[1][j], FB[0][j], acc[1][0], 0, 0, 0);   \
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[1][j], FB[1][j], acc[1][1], 0, 0, 0);   \
+  } while (0)
+  // k-step: [4 ds_read of the next fragments] 16 MFMA
+#define DMDX_KSTEP(FA, FB, i)                                      \
+  do {                                                             \
+    DMDX_MFMA4(FA, FB, 0);                                         \
+    DMDX_MFMA4(FA, FB, 1);                                         \
+    DMDX_MFMA4(FA, FB, 2);                                         \
+    DMDX_MFMA4(FA, FB, 3);                                         \
+    __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);            \
+  } while (0)
+
   int cur = 0;
   for (int c = 0; c < nchunks; ++c) {
-    const bool has_next = (c + 1 < nchunks);
-    if (has_next) load_stage(c_begin + c + 1);
-    const int phase = c & 7, fq = (c >> 3) & 3;
-    if (phase == 6 && c >= 32) {  // old partial values of block fq, used one chunk later
+    const bool has_next = (c + 1 < nchunks) && !(ABL & 1);
+    const bool dma_next = DMA && has_next && (c_begin + c + 1 != tail_chunk);
+    const int64_t knext = (int64_t)(c_begin + c + 1) * BK;
+    float* dma_as = lds + ((cur ^ 1) * 2 + 0) * OPSZ + (32 * wave) * BK;
+    float* dma_bs = lds + ((cur ^ 1) * 2 + 1) * OPSZ + (32 * wave) * BK;
+    const int phase = c & (FOLD / 4 - 1), fq = (c / (FOLD / 4)) & 3;
+    if (!(ABL & 8) && phase == FOLD / 4 - 2 && c >= FOLD) {  // old partial values of block fq, used one chunk later
       switch (fq) {
         case 0: DMDX_PREFETCH(0, 0); break;
         case 1: DMDX_PREFETCH(0, 1); break;
@@ -271,26 +336,27 @@ __global__ __launch_bounds__(NTH, 2) void gemm_tn_partial_kernel(TnParams p) {
       }
     }
 
+    DMDX_DMA_PAIR(0);
+    DMDX_DMA_PAIR(1);
+    DMDX_DMA_PAIR(2);
+    DMDX_DMA_PAIR(3);
     DMDX_READ_FRAGS(fa1, fb1, cur, 1);
     __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);   // 4 ds_read
-    DMDX_MFMA16(fa0, fb0);
-    __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);  // 16 mfma
+    DMDX_KSTEP(fa0, fb0, 0);
     DMDX_READ_FRAGS(fa0, fb0, cur, 2);
     __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-    DMDX_MFMA16(fa1, fb1);
-    __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+    DMDX_KSTEP(fa1, fb1, 1);
     DMDX_READ_FRAGS(fa1, fb1, cur, 3);
     __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-    DMDX_MFMA16(fa0, fb0);
-    __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
-    DMDX_MFMA16(fa1, fb1);
+    DMDX_KSTEP(fa0, fb0, 2);
+    DMDX_KSTEP(fa1, fb1, 3);
+    if (has_next && !dma_next) stage_regs(c_begin + c + 1, cur ^ 1, c_begin + c + 1 == tail_chunk);
 
-    if (has_next) store_stage(cur ^ 1);
-    __syncthreads();
+    if (!(ABL & 2)) __syncthreads();  // waits for this wave's LDS-DMA (vmcnt) and for every wave's reads of `cur`
     cur ^= 1;
     if (has_next) DMDX_READ_FRAGS(fa0, fb0, cur, 0);
-    if (phase == 7) {
-      if (c >= 32) {
+    if (!(ABL & 8) && phase == FOLD / 4 - 1) {
+      if (c >= FOLD) {
         switch (fq) {
           case 0: DMDX_COMMIT(0, 0, true); break;
           case 1: DMDX_COMMIT(0, 1, true); break;
@@ -307,14 +373,17 @@ __global__ __launch_bounds__(NTH, 2) void gemm_tn_partial_kernel(TnParams p) {
       }
     }
   }
-  // final fold of whatever each block still holds (block q was folded before iff
-  // the unit ran at least 8q+8 chunks)
-  if (nchunks >= 8) { DMDX_PREFETCH(0, 0); DMDX_COMMIT(0, 0, true); } else { DMDX_COMMIT(0, 0, false); }
-  if (nchunks >= 16) { DMDX_PREFETCH(0, 1); DMDX_COMMIT(0, 1, true); } else { DMDX_COMMIT(0, 1, false); }
-  if (nchunks >= 24) { DMDX_PREFETCH(1, 0); DMDX_COMMIT(1, 0, true); } else { DMDX_COMMIT(1, 0, false); }
-  if (nchunks >= 32) { DMDX_PREFETCH(1, 1); DMDX_COMMIT(1, 1, true); } else { DMDX_COMMIT(1, 1, false); }
+  // final fold of whatever each block still holds (block q was folded before iff the
+  // unit ran at least (q+1)*FOLD/4 chunks)
+  if (nchunks >= 1 * (FOLD / 4)) { DMDX_PREFETCH(0, 0); DMDX_COMMIT(0, 0, true); } else { DMDX_COMMIT(0, 0, false); }
+  if (nchunks >= 2 * (FOLD / 4)) { DMDX_PREFETCH(0, 1); DMDX_COMMIT(0, 1, true); } else { DMDX_COMMIT(0, 1, false); }
+  if (nchunks >= 3 * (FOLD / 4)) { DMDX_PREFETCH(1, 0); DMDX_COMMIT(1, 0, true); } else { DMDX_COMMIT(1, 0, false); }
+  if (nchunks >= 4 * (FOLD / 4)) { DMDX_PREFETCH(1, 1); DMDX_COMMIT(1, 1, true); } else { DMDX_COMMIT(1, 1, false); }
 #undef DMDX_READ_FRAGS
 #undef DMDX_MFMA16
+#undef DMDX_MFMA4
+#undef DMDX_KSTEP
+#undef DMDX_DMA_PAIR
 #undef DMDX_PREFETCH
 #undef DMDX_COMMIT
 #undef DMDX_BLOCK_OFF
@@ -334,10 +403,10 @@ __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(
   if (syrk) {
     decode_tri(tile, ntr, ta, tb);
   } else {
-    int per_sr = 4 * ntc;
+    int per_sr = SR * ntc;
     int sr = tile / per_sr;
-    int r0 = sr * 4;
-    int nrows = ntr - r0 < 4 ? ntr - r0 : 4;
+    int r0 = sr * SR;
+    int nrows = ntr - r0 < SR ? ntr - r0 : SR;
     int tt = tile - sr * per_sr;
     tb = tt / nrows;
     ta = r0 + tt % nrows;
@@ -395,8 +464,14 @@ Plan make_plan(int64_t K, int64_t nrow, int64_t ncol, int syrk) {
   pl.ntiles = syrk ? pl.ntr * (pl.ntr + 1) / 2 : pl.ntr * pl.ntc;
   pl.chunks_total = (int)((K + BK - 1) / BK);
   if (pl.chunks_total < 1) pl.chunks_total = 1;
-  // aim at >= ~20 rounds of 512 resident workgroups, keep >= 8 chunks per split
+  // aim at >= ~20 rounds of 512 resident workgroups, keep >= 8 chunks per split, and
+  // keep units short enough (<= max_cps chunks) that the workgroups sharing panels in
+  // L2 / Infinity Cache do not drift apart along K
+  int64_t max_cps = 1024;  // 256 measured +0.8 % but needs 4x the workspace
+  if (const char* e = getenv("DMDX_TN_MAX_CPS")) max_cps = atoll(e) > 0 ? atoll(e) : max_cps;
   int64_t want = (20 * 512 + pl.ntiles - 1) / pl.ntiles;
+  int64_t by_len = (pl.chunks_total + max_cps - 1) / max_cps;
+  if (want < by_len) want = by_len;
   int64_t maxs = pl.chunks_total / 8;
   if (maxs < 1) maxs = 1;
   if (want > maxs) want = maxs;
@@ -425,7 +500,19 @@ int run_tn(const float* A, int64_t lda, const float* B, int64_t ldb, int64_t K, 
   p.P = reinterpret_cast<double*>(ws);
   const bool aligned = (lda % 4 == 0) && (ldb % 4 == 0) && dmdx_aligned16(A) && dmdx_aligned16(B);
   dim3 grid((unsigned)((size_t)pl.nsplit * pl.ntiles));
-  if (aligned)
+  int abl = 0;
+  if (const char* e = getenv("DMDX_TN_ABLATE")) abl = atoi(e);
+  if (aligned && abl == 1)
+    hipLaunchKernelGGL((gemm_tn_partial_kernel<true, 1>), grid, dim3(NTH), 0, stream, p);
+  else if (aligned && abl == 2)
+    hipLaunchKernelGGL((gemm_tn_partial_kernel<true, 2>), grid, dim3(NTH), 0, stream, p);
+  else if (aligned && abl == 8)
+    hipLaunchKernelGGL((gemm_tn_partial_kernel<true, 8>), grid, dim3(NTH), 0, stream, p);
+  else if (aligned && abl == 4)
+    hipLaunchKernelGGL((gemm_tn_partial_kernel<true, 4>), grid, dim3(NTH), 0, stream, p);
+  else if (aligned && abl == 11)
+    hipLaunchKernelGGL((gemm_tn_partial_kernel<true, 11>), grid, dim3(NTH), 0, stream, p);
+  else if (aligned)  // LDS-DMA staging needs 16-byte aligned column starts
     hipLaunchKernelGGL(gemm_tn_partial_kernel<true>, grid, dim3(NTH), 0, stream, p);
   else
     hipLaunchKernelGGL(gemm_tn_partial_kernel<false>, grid, dim3(NTH), 0, stream, p);

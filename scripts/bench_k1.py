@@ -4,7 +4,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dmd_era5_amd.kernels import default_kernels
 ap = argparse.ArgumentParser()
-ap.add_argument("--m", type=int, default=262144)
+ap.add_argument("--m", type=int, default=259560)
 ap.add_argument("--n", type=int, default=8760)
 ap.add_argument("--reps", type=int, default=3)
 a = ap.parse_args()

@@ -12,7 +12,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdmdx.so")
+# DMDX_LIB_PATH: A/B experiments load an alternative build of the same ABI
+LIB_PATH = os.environ.get("DMDX_LIB_PATH") or os.path.join(_HERE, "libdmdx.so")
 
 _i64 = C.c_int64
 _p = C.c_void_p
@@ -23,11 +24,11 @@ SIGNATURES = {
     "dmdx_version": (C.c_int, []),
     "dmdx_last_error": (C.c_char_p, []),
     "dmdx_syrk_workspace_bytes": (_sz, [_i64, _i64]),
-    "dmdx_syrk_f32": (C.c_int, [_p, _i64, _i64, _i64, _p, _i64, _p, _i64, _p, _sz, _p]),
+    "dmdx_syrk_f32": (C.c_int, [_p, _i64, _i64, _i64, _p, _i64, _p, _i64, C.c_int, _p, _sz, _p]),
     "dmdx_gemm_tn_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "dmdx_gemm_tn_f32": (
         C.c_int,
-        [_p, _i64, _p, _i64, _i64, _i64, _i64, _p, _i64, _p, _i64, _p, _sz, _p],
+        [_p, _i64, _p, _i64, _i64, _i64, _i64, _p, _i64, _p, _i64, C.c_int, _p, _sz, _p],
     ),
     "dmdx_gemm_nn_skinny_f32": (C.c_int, [_p, _i64, _i64, _i64, _p, _i64, _i64, _p, _i64, _p]),
     "dmdx_row_center_scale_f32": (C.c_int, [_p, _i64, _i64, _i64, _p, _p, C.c_int, _p]),

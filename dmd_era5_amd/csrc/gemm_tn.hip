@@ -394,7 +394,7 @@ __global__ __launch_bounds__(NTH, 2) void gemm_tn_partial_kernel(TnParams p) {
 // roles swapped by the host wrapper).  SYRK mode also writes the mirror.
 __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(
     const double* P, int nsplit, int ntiles, int ntr, int ntc, int syrk, int nrow, int ncol,
-    double* D64, int64_t ld64, float* D32, int64_t ld32) {
+    double* D64, int64_t ld64, float* D32, int64_t ld32, int accumulate) {
   __shared__ double tr[32][33];
   // one workgroup per (tile, 32x32 sub-block)
   const int tile = blockIdx.x >> 4;
@@ -430,8 +430,10 @@ __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(
     const int gi = row0 + i, gj = col0 + j;
     const bool keep = !(diag && i > j);
     if (keep && gi < nrow && gj < ncol) {
-      D64[(int64_t)gi * ld64 + gj] = v[k];
-      if (D32) D32[(int64_t)gi * ld32 + gj] = (float)v[k];
+      double o = v[k];
+      if (accumulate) o += D64[(int64_t)gi * ld64 + gj];
+      D64[(int64_t)gi * ld64 + gj] = o;
+      if (D32) D32[(int64_t)gi * ld32 + gj] = (float)o;
     }
     tr[ty + 8 * k][tx] = v[k];
   }
@@ -445,8 +447,10 @@ __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(
       const int gi = row0 + i, gj = col0 + j;
       const bool keep = !(diag && i >= j);
       if (keep && gi < nrow && gj < ncol) {
-        D64[(int64_t)gj * ld64 + gi] = s;
-        if (D32) D32[(int64_t)gj * ld32 + gi] = (float)s;
+        double o = s;
+        if (accumulate) o += D64[(int64_t)gj * ld64 + gi];
+        D64[(int64_t)gj * ld64 + gi] = o;
+        if (D32) D32[(int64_t)gj * ld32 + gi] = (float)o;
       }
     }
   }
@@ -484,8 +488,8 @@ Plan make_plan(int64_t K, int64_t nrow, int64_t ncol, int syrk) {
 }
 
 int run_tn(const float* A, int64_t lda, const float* B, int64_t ldb, int64_t K, int64_t nrow,
-           int64_t ncol, int syrk, double* D64, int64_t ld64, float* D32, int64_t ld32, void* ws,
-           size_t ws_bytes, hipStream_t stream) {
+           int64_t ncol, int syrk, double* D64, int64_t ld64, float* D32, int64_t ld32,
+           int accumulate, void* ws, size_t ws_bytes, hipStream_t stream) {
   Plan pl = make_plan(K, nrow, ncol, syrk);
   if (ws == nullptr || ws_bytes < pl.ws_bytes) {
     dmdx_set_error("gemm_tn: workspace %zu bytes < required %zu", ws_bytes, pl.ws_bytes);
@@ -518,7 +522,7 @@ int run_tn(const float* A, int64_t lda, const float* B, int64_t ldb, int64_t K, 
     hipLaunchKernelGGL(gemm_tn_partial_kernel<false>, grid, dim3(NTH), 0, stream, p);
   DMDX_LAUNCH_CHECK();
   hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3(pl.ntiles * 16), dim3(256), 0, stream, p.P, pl.nsplit,
-                     pl.ntiles, pl.ntr, pl.ntc, syrk, (int)nrow, (int)ncol, D64, ld64, D32, ld32);
+                     pl.ntiles, pl.ntr, pl.ntc, syrk, (int)nrow, (int)ncol, D64, ld64, D32, ld32, accumulate);
   DMDX_LAUNCH_CHECK();
   return 0;
 }
@@ -533,13 +537,13 @@ size_t dmdx_syrk_workspace_bytes(int64_t m, int64_t n) {
 }
 
 int dmdx_syrk_f32(const float* X, int64_t m, int64_t n, int64_t ldx, double* G64, int64_t ldg,
-                  float* G32, int64_t ldg32, void* workspace, size_t workspace_bytes,
-                  void* stream) {
+                  float* G32, int64_t ldg32, int accumulate, void* workspace,
+                  size_t workspace_bytes, void* stream) {
   DMDX_CHECK_ARG(X && G64, "syrk: null pointer");
   DMDX_CHECK_ARG(m >= 1 && n >= 1 && n < (1 << 30), "syrk: bad shape m=%lld n=%lld", (long long)m,
                  (long long)n);
   DMDX_CHECK_ARG(ldx >= 1 && ldg >= n && (!G32 || ldg32 >= n), "syrk: bad leading dimension");
-  return run_tn(X, ldx, X, ldx, m, n, n, 1, G64, ldg, G32, ldg32, workspace, workspace_bytes,
+  return run_tn(X, ldx, X, ldx, m, n, n, 1, G64, ldg, G32, ldg32, accumulate, workspace, workspace_bytes,
                 (hipStream_t)stream);
 }
 
@@ -550,14 +554,14 @@ size_t dmdx_gemm_tn_workspace_bytes(int64_t K, int64_t na, int64_t nb) {
 
 int dmdx_gemm_tn_f32(const float* A, int64_t lda, const float* B, int64_t ldb, int64_t K,
                      int64_t na, int64_t nb, double* C64, int64_t ldc, float* C32, int64_t ldc32,
-                     void* workspace, size_t workspace_bytes, void* stream) {
+                     int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
   DMDX_CHECK_ARG(A && B && C64, "gemm_tn: null pointer");
   DMDX_CHECK_ARG(K >= 1 && na >= 1 && nb >= 1 && na < (1 << 30) && nb < (1 << 30),
                  "gemm_tn: bad shape");
   DMDX_CHECK_ARG(lda >= 1 && ldb >= 1 && ldc >= na && (!C32 || ldc32 >= na),
                  "gemm_tn: bad leading dimension");
   // column-major C[a + b*ldc] == row-major D[b][a]: D rows <- B columns, D cols <- A columns
-  return run_tn(B, ldb, A, lda, K, nb, na, 0, C64, ldc, C32, ldc32, workspace, workspace_bytes,
+  return run_tn(B, ldb, A, lda, K, nb, na, 0, C64, ldc, C32, ldc32, accumulate, workspace, workspace_bytes,
                 (hipStream_t)stream);
 }
 

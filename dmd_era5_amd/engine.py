@@ -27,6 +27,17 @@ def to_device_matrix(X: np.ndarray, device: torch.device | str = "cuda") -> torc
     return torch.from_numpy(Xt_host).to(device)
 
 
+def to_device_blocks(X: np.ndarray, device: torch.device | str = "cuda") -> list[torch.Tensor]:
+    """numpy (space, time) -> list of device row blocks, each (time, rows) fp32 (the
+    layout the kernels want for large m, see svd.BLOCK_ROWS).  Uploads block by block."""
+    if X.ndim != 2:
+        raise ValueError("X must be 2-D (space, time)")
+    m = X.shape[0]
+    if m <= 2 * _svd.BLOCK_ROWS:
+        return [to_device_matrix(X, device)]
+    return [to_device_matrix(X[a:b], device) for a, b in _svd.split_rows(m)]
+
+
 def _flip_by_u(U: np.ndarray, V: np.ndarray):
     idx = np.argmax(np.abs(U), axis=0)
     sg = np.sign(U[idx, np.arange(U.shape[1])])
@@ -49,9 +60,9 @@ def svd_numpy(X: np.ndarray, svd_type: str, n_components: int, device="cuda", **
     if wide:
         # sklearn transposes wide inputs (extmath.py:562-566); LAPACK does not care.
         # The tall algorithms run on X^T and the factors swap roles.
-        Xt = to_device_matrix(np.ascontiguousarray(X.T), device)  # (space, time) tensor
+        Xt = to_device_blocks(np.ascontiguousarray(X.T), device)  # (space, time) tensors
     else:
-        Xt = to_device_matrix(X, device)
+        Xt = to_device_blocks(X, device)
     if svd_type == "standard":
         res = _svd.svd_snapshots(Xt, n_components, flip_sign=not wide, **opts)
     else:

@@ -76,21 +76,31 @@ class HipKernels:
         return ws
 
     # -- K1 -----------------------------------------------------------------
-    def syrk(self, Xt: torch.Tensor, want32: bool = False):
-        """G = X^T X (fp64, both triangles).  Xt: (n, m) fp32.  -> G64 [, G32]."""
+    def syrk(self, Xt: torch.Tensor, want32: bool = False, out: torch.Tensor | None = None):
+        """G = X^T X (fp64, both triangles).  Xt: (n, m) fp32.  -> G64 [, G32].
+
+        ``out``: an (n, n) fp64 tensor to accumulate into (G64 = out += X^T X): the
+        Gram of a row-blocked snapshot matrix is the sum over its blocks."""
         m, n, ld = _check_mat(Xt, torch.float32, "syrk X")
-        G64 = torch.empty((n, n), dtype=torch.float64, device=Xt.device)
+        if out is not None:
+            if out.shape != (n, n) or out.dtype != torch.float64 or not out.is_contiguous():
+                raise _lib.DmdxError("syrk: out must be a contiguous (n, n) fp64 tensor")
+            G64 = out
+        else:
+            G64 = torch.empty((n, n), dtype=torch.float64, device=Xt.device)
         G32 = torch.empty((n, n), dtype=torch.float32, device=Xt.device) if want32 else None
         nbytes = self._lib.dmdx_syrk_workspace_bytes(m, n)
         ws = self._workspace(Xt.device, nbytes)
         rc = self._timed("syrk", (m, n), lambda: self._lib.dmdx_syrk_f32(
-            _ptr(Xt), m, n, ld, _ptr(G64), n, _ptr(G32), n, _ptr(ws), ws.numel(), self._stream()
+            _ptr(Xt), m, n, ld, _ptr(G64), n, _ptr(G32), n, int(out is not None), _ptr(ws),
+            ws.numel(), self._stream()
         ))
         _lib.check(rc, "dmdx_syrk_f32")
         return (G64, G32) if want32 else G64
 
     # -- K3 -----------------------------------------------------------------
-    def gemm_tn(self, At: torch.Tensor, Bt: torch.Tensor, want32: bool = False):
+    def gemm_tn(self, At: torch.Tensor, Bt: torch.Tensor, want32: bool = False,
+                out: torch.Tensor | None = None):
         """C = A^T B for K-contiguous A (K x na), B (K x nb).
 
         At: (na, K), Bt: (nb, K) fp32.  Returns Ct of shape (nb, na) (the
@@ -99,13 +109,18 @@ class HipKernels:
         Kb, nb, ldb = _check_mat(Bt, torch.float32, "gemm_tn B")
         if Ka != Kb:
             raise _lib.DmdxError(f"gemm_tn: K mismatch {Ka} vs {Kb}")
-        C64 = torch.empty((nb, na), dtype=torch.float64, device=At.device)
+        if out is not None:
+            if out.shape != (nb, na) or out.dtype != torch.float64 or not out.is_contiguous():
+                raise _lib.DmdxError("gemm_tn: out must be a contiguous (nb, na) fp64 tensor")
+            C64 = out
+        else:
+            C64 = torch.empty((nb, na), dtype=torch.float64, device=At.device)
         C32 = torch.empty((nb, na), dtype=torch.float32, device=At.device) if want32 else None
         nbytes = self._lib.dmdx_gemm_tn_workspace_bytes(Ka, na, nb)
         ws = self._workspace(At.device, nbytes)
         rc = self._timed("gemm_tn", (Ka, na, nb), lambda: self._lib.dmdx_gemm_tn_f32(
             _ptr(At), lda, _ptr(Bt), ldb, Ka, na, nb, _ptr(C64), na, _ptr(C32), na,
-            _ptr(ws), ws.numel(), self._stream(),
+            int(out is not None), _ptr(ws), ws.numel(), self._stream(),
         ))
         _lib.check(rc, "dmdx_gemm_tn_f32")
         return (C64, C32) if want32 else C64

@@ -38,6 +38,8 @@ __all__ = [
     "TorchDistComm",
     "SvdResult",
     "embed_view",
+    "as_blocks",
+    "split_rows",
     "top_eigh",
     "svd_snapshots",
     "svd_randomized",
@@ -174,19 +176,92 @@ def top_eigh(G: torch.Tensor, l: int, method: str = "auto", tol: float = 1e-11,
     return top_eigh(G, l, method="full", info=info)
 
 
-def _sign_flip(Ut: torch.Tensor, Vh: torch.Tensor, comm: Comm, kern):
+# ---------------------------------------------------------------------------
+# row (space) blocks
+# ---------------------------------------------------------------------------
+# A 1 038 240-row fp32 snapshot has a 4 MB column stride: the 256 columns a Gram
+# tile touches per K-step then live in 256 different 2 MB pages and the per-CU
+# TLB thrashes (measured: 32 % UTCL1 misses, -10 % Gram throughput).  The engine
+# therefore keeps X in HBM as row blocks of at most BLOCK_ROWS space points, each
+# a contiguous (time, rows) tensor; Gram / projections are sums / concatenations
+# over the blocks.  (It is also exactly the shape of a multi-GPU row shard.)
+BLOCK_ROWS = 131072
+
+
+def split_rows(m: int, block_rows: int | None = None) -> list[tuple[int, int]]:
+    """[(start, stop)] of nearly equal row blocks, each a multiple of 4 rows when m is."""
+    block_rows = block_rows or BLOCK_ROWS
+    nb = max(1, -(-m // block_rows))
+    base = -(-m // nb)
+    if m % 4 == 0:
+        base = -(-base // 4) * 4
+    out, r = [], 0
+    while r < m:
+        out.append((r, min(m, r + base)))
+        r += base
+    return out
+
+
+def as_blocks(Xt) -> list[torch.Tensor]:
+    """Normalise the snapshot-matrix argument to a list of (time, rows) blocks.
+    A single tensor wider than BLOCK_ROWS is re-blocked (device copy)."""
+    if isinstance(Xt, (list, tuple)):
+        return list(Xt)
+    n, m = Xt.shape
+    if m <= 2 * BLOCK_ROWS:
+        return [Xt]
+    return [Xt[:, a:b].contiguous() for a, b in split_rows(m)]
+
+
+def _gram_blocks(blocks, kern, comm: Comm) -> torch.Tensor:
+    G = None
+    for B in blocks:
+        G = kern.syrk(B) if G is None else kern.syrk(B, out=G)
+    return comm.allreduce_sum_(G)
+
+
+def _gemm_tn_blocks(Ablocks, Bblocks, kern, comm: Comm) -> torch.Tensor:
+    C = None
+    for A, B in zip(Ablocks, Bblocks):
+        C = kern.gemm_tn(A, B) if C is None else kern.gemm_tn(A, B, out=C)
+    return comm.allreduce_sum_(C)
+
+
+def _assemble_rows(Ublocks, d: int) -> torch.Tensor:
+    """Concatenate per-block results (k, d*mb_b) into (k, d*m) in the reference's
+    embedded row order k_delay*m + s (slice_tools.py:207-211)."""
+    if len(Ublocks) == 1:
+        return Ublocks[0]
+    if d == 1:
+        return torch.cat(Ublocks, dim=1)
+    parts = []
+    for kd in range(d):
+        for U in Ublocks:
+            mb = U.shape[1] // d
+            parts.append(U[:, kd * mb:(kd + 1) * mb])
+    return torch.cat(parts, dim=1)
+
+
+def _sign_flip(Ublocks, Vh: torch.Tensor, comm: Comm, kern):
     """u-based sign convention of sklearn's svd_flip (extmath.py:935-943): the
     largest-|.| entry of every left singular vector becomes positive."""
-    idx = Ut.abs().argmax(dim=1, keepdim=True)
-    val = Ut.gather(1, idx).squeeze(1)
+    vals = []
+    for Ut in Ublocks:
+        idx = Ut.abs().argmax(dim=1, keepdim=True)
+        vals.append(Ut.gather(1, idx).squeeze(1))
     if comm.world_size > 1:
-        allv = torch.stack(comm.allgather(val.contiguous()), dim=0)  # (world, k)
-        pick = allv.abs().argmax(dim=0, keepdim=True)
-        val = allv.gather(0, pick).squeeze(0)
+        gathered = []
+        for v in vals:
+            gathered.extend(comm.allgather(v.contiguous()))
+        vals = gathered
+    allv = torch.stack(vals, dim=0)  # (blocks x world, k)
+    pick = allv.abs().argmax(dim=0, keepdim=True)
+    val = allv.gather(0, pick).squeeze(0)
     sign = torch.where(val < 0, -torch.ones_like(val), torch.ones_like(val))
-    kern.scale_columns_(Ut, sign.to(torch.float32))
+    for Ut in Ublocks:
+        kern.scale_columns_(Ut, sign.to(torch.float32))
     Vh = Vh * sign.to(Vh.dtype)[:, None]
-    return Ut, Vh
+    return Ublocks, Vh
 
 
 def _sync_time(device) -> float:
@@ -198,28 +273,29 @@ def _sync_time(device) -> float:
 # ---------------------------------------------------------------------------
 # "standard": method of snapshots
 # ---------------------------------------------------------------------------
-def svd_snapshots(Xt: torch.Tensor, n_components: int, delay: int = 1, oversample: int | None = None,
+def svd_snapshots(Xt, n_components: int, delay: int = 1, oversample: int | None = None,
                   refine: bool = True, flip_sign: bool = True, comm: Comm | None = None,
                   kern=None, eig_method: str = "auto", timings: bool = False) -> SvdResult:
     """Rank-k SVD of the (delay-embedded) snapshot matrix by the Gram route.
 
-    Xt: (n, m_local) fp32 device tensor, already pre-processed (centred/scaled).
-    Returns local rows of U; s and V are replicated on every rank.
+    Xt: (n, m_local) fp32 device tensor -- or a list of such row blocks --
+    already pre-processed (centred/scaled).  Returns local rows of U; s and V
+    are replicated on every rank.
     """
     kern = _kern(kern)
     comm = comm or Comm()
     info: dict = {}
-    dev = Xt.device
+    blocks = as_blocks(Xt)
+    dev = blocks[0].device
     t0 = _sync_time(dev) if timings else 0.0
 
-    G = kern.syrk(Xt)
-    comm.allreduce_sum_(G)
+    G = _gram_blocks(blocks, kern, comm)
     if delay > 1:
         G = kern.delay_shift_sum(G, delay)
     nd = G.shape[0]
     t1 = _sync_time(dev) if timings else 0.0
 
-    Mg = Xt.shape[1] * delay
+    Mg = sum(B.shape[1] for B in blocks) * delay
     if comm.world_size > 1:
         tot = torch.tensor([Mg], dtype=torch.int64, device=dev)
         comm.allreduce_sum_(tot)
@@ -235,16 +311,14 @@ def svd_snapshots(Xt: torch.Tensor, n_components: int, delay: int = 1, oversampl
     s0 = torch.where(good, s0, torch.zeros_like(s0))
     t2 = _sync_time(dev) if timings else 0.0
 
-    Et = embed_view(Xt, delay)
-    Wt = (V * inv_s0).T.contiguous().to(torch.float32)  # (l, nd)
-    Upt = kern.skinny(Et, Wt)                            # (l, M): U' = X V S^-1
+    Wt = (V * inv_s0).T.contiguous().to(torch.float32)           # (l, nd)
+    Up = [kern.skinny(embed_view(B, delay), Wt) for B in blocks]  # (l, d*mb): U' = X V S^-1
     t3 = _sync_time(dev) if timings else 0.0
 
     if refine:
         # Rayleigh-Ritz in span(V): (XV)^T (XV) = S (U'^T U') S, graded by S so the
         # small singular values keep their relative accuracy.
-        Mm = kern.syrk(Upt)                              # (l, l) fp64
-        comm.allreduce_sum_(Mm)
+        Mm = _gram_blocks(Up, kern, comm)                         # (l, l) fp64
         T = s0[:, None] * Mm * s0[None, :]
         T = 0.5 * (T + T.T)
         mu, Z = torch.linalg.eigh(T)
@@ -253,42 +327,45 @@ def svd_snapshots(Xt: torch.Tensor, n_components: int, delay: int = 1, oversampl
         s = torch.sqrt(mu.clamp_min(0.0))
         ok = s > s0[0] * 1e-7
         inv_s = torch.where(ok, 1.0 / torch.where(ok, s, torch.ones_like(s)), torch.zeros_like(s))
-        Rm = (s0[:, None] * Z) * inv_s[None, :]          # (l, k): U = U' R
-        Ut = kern.skinny(Upt, Rm.T.contiguous().to(torch.float32))  # (k, M)
+        Rm = (s0[:, None] * Z) * inv_s[None, :]                   # (l, k): U = U' R
+        Rt = Rm.T.contiguous().to(torch.float32)
+        Ub = [kern.skinny(U, Rt) for U in Up]                     # (k, d*mb)
         Vh = (V @ Z).T.contiguous()
     else:
         s = s0[:k]
-        Ut = Upt[:k]
+        Ub = [U[:k] for U in Up]
         Vh = V[:, :k].T.contiguous()
     if flip_sign:
-        Ut, Vh = _sign_flip(Ut, Vh, comm, kern)
+        Ub, Vh = _sign_flip(Ub, Vh, comm, kern)
+    Ut = _assemble_rows(Ub, delay)
     if timings:
         t4 = _sync_time(dev)
         info.update(t_gram=t1 - t0, t_eig=t2 - t1, t_project=t3 - t2, t_refine=t4 - t3,
                     t_total=t4 - t0)
-    info.update(l=l, k=k, nd=nd)
+    info.update(l=l, k=k, nd=nd, row_blocks=len(blocks))
     return SvdResult(Ut=Ut, s=s, Vh=Vh, info=info)
 
 
 # ---------------------------------------------------------------------------
 # "randomized": sklearn's range finder with CholeskyQR normalisers
 # ---------------------------------------------------------------------------
-def _cholqr(Yt: torch.Tensor, comm: Comm, kern, passes: int = 1) -> torch.Tensor:
-    """Orthonormalise the columns of the tall matrix Y (Yt: (l, M)): G = Y^T Y
-    (l x l, all-reduced), G = R^T R, Y <- Y R^-1."""
-    l = Yt.shape[0]
-    eye = torch.eye(l, dtype=torch.float64, device=Yt.device)
+def _cholqr(Yb, comm: Comm, kern, passes: int = 1):
+    """Orthonormalise the columns of the tall matrix Y given as row blocks
+    (each (l, M_b)): G = Y^T Y (l x l, summed over blocks and ranks), G = R^T R,
+    Y <- Y R^-1."""
+    l = Yb[0].shape[0]
+    eye = torch.eye(l, dtype=torch.float64, device=Yb[0].device)
     for _ in range(passes):
-        G = kern.syrk(Yt)
-        comm.allreduce_sum_(G)
+        G = _gram_blocks(Yb, kern, comm)
         G = 0.5 * (G + G.T)
         L, err = torch.linalg.cholesky_ex(G)
         if int(err) != 0:  # numerically rank deficient: shift (keeps the span)
             shift = 1e-12 * torch.diagonal(G).sum()
             L = torch.linalg.cholesky(G + shift * eye)
         Rinv = torch.linalg.solve_triangular(L.T, eye, upper=True)  # R = L^T
-        Yt = kern.skinny(Yt, Rinv.T.contiguous().to(torch.float32))
-    return Yt
+        Rt = Rinv.T.contiguous().to(torch.float32)
+        Yb = [kern.skinny(Y, Rt) for Y in Yb]
+    return Yb
 
 
 def resolve_n_iter(n_components: int, m: int, n: int, n_iter="auto") -> int:
@@ -298,7 +375,7 @@ def resolve_n_iter(n_components: int, m: int, n: int, n_iter="auto") -> int:
     return int(n_iter)
 
 
-def svd_randomized(Xt: torch.Tensor, n_components: int, delay: int = 1, n_oversamples: int = 10,
+def svd_randomized(Xt, n_components: int, delay: int = 1, n_oversamples: int = 10,
                    n_iter="auto", power_iteration_normalizer: str = "auto",
                    omega: np.ndarray | torch.Tensor | None = None, random_state=None,
                    flip_sign: bool = True, comm: Comm | None = None, kern=None,
@@ -312,9 +389,11 @@ def svd_randomized(Xt: torch.Tensor, n_components: int, delay: int = 1, n_oversa
     kern = _kern(kern)
     comm = comm or Comm()
     info: dict = {}
-    dev = Xt.device
-    Et = embed_view(Xt, delay)
-    nd, M = Et.shape
+    blocks = as_blocks(Xt)
+    dev = blocks[0].device
+    Eb = [embed_view(B, delay) for B in blocks]
+    nd = Eb[0].shape[0]
+    M = sum(E.shape[1] for E in Eb)
     Mg = M
     if comm.world_size > 1:
         tot = torch.tensor([M], dtype=torch.int64, device=dev)
@@ -348,27 +427,27 @@ def svd_randomized(Xt: torch.Tensor, n_components: int, delay: int = 1, n_oversa
     t0 = _sync_time(dev) if timings else 0.0
 
     for _ in range(n_it):
-        Yt = kern.skinny(Et, Qt)                 # Y = X Q            (extmath.py:350)
+        Yb = [kern.skinny(E, Qt) for E in Eb]    # Y = X Q            (extmath.py:350)
         if normalise:
-            Yt = _cholqr(Yt, comm, kern)
-        Zt = kern.gemm_tn(Et, Yt)                # Z = X^T Y, (l, nd) (extmath.py:351)
-        comm.allreduce_sum_(Zt)
+            Yb = _cholqr(Yb, comm, kern)
+        Zt = _gemm_tn_blocks(Eb, Yb, kern, comm)  # Z = X^T Y, (l, nd) (extmath.py:351)
         if normalise:
             Qt = _orth(Zt.T).T.contiguous().to(torch.float32)
         else:
             Qt = Zt.to(torch.float32)
-    Yt = kern.skinny(Et, Qt)                     # extmath.py:355
-    Qmt = _cholqr(Yt, comm, kern, passes=2)      # orthonormal basis of range(Y)
-    Bm = kern.gemm_tn(Et, Qmt)                   # (l, nd) = Q^T X    (extmath.py:577)
-    comm.allreduce_sum_(Bm)
+    Yb = [kern.skinny(E, Qt) for E in Eb]        # extmath.py:355
+    Qmb = _cholqr(Yb, comm, kern, passes=2)      # orthonormal basis of range(Y)
+    Bm = _gemm_tn_blocks(Eb, Qmb, kern, comm)    # (l, nd) = Q^T X    (extmath.py:577)
     Uhat, s, Vh = torch.linalg.svd(Bm, full_matrices=False)
-    Ut = kern.skinny(Qmt, Uhat[:, :k].T.contiguous().to(torch.float32))  # U = Q Uhat
+    Uk = Uhat[:, :k].T.contiguous().to(torch.float32)
+    Ub = [kern.skinny(Q, Uk) for Q in Qmb]       # U = Q Uhat
     s = s[:k]
     Vh = Vh[:k].contiguous()
     if flip_sign:
-        Ut, Vh = _sign_flip(Ut, Vh, comm, kern)
+        Ub, Vh = _sign_flip(Ub, Vh, comm, kern)
+    Ut = _assemble_rows(Ub, delay)
     if timings:
         info["t_total"] = _sync_time(dev) - t0
     info.update(l=l, k=k, nd=nd, n_iter=n_it, normalizer=power_iteration_normalizer,
-                passes_over_X=2 * n_it + 2)
+                passes_over_X=2 * n_it + 2, row_blocks=len(blocks))
     return SvdResult(Ut=Ut, s=s, Vh=Vh, info=info)

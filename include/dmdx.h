@@ -49,11 +49,16 @@ const char* dmdx_last_error(void);
  * Takes over the O(m n^2) part of np.linalg.svd (era5_svd.py:251).
  * X: m x n fp32 (ldx), G64: n x n fp64 (ldg), both triangles written.
  * G32 (nullable): fp32 copy of G (ldg32).
- * fp32 MFMA products, fp32 chains of at most 1024 rows, fp64 across chains.
+ * accumulate != 0: G64 += X^T X (G32, if given, receives the rounded new G64): the
+ * snapshot matrix is kept in HBM as row (space) blocks with a short leading
+ * dimension -- a 4 MB column stride makes every 128-byte access of a 128-column
+ * panel hit a different 2 MB page and thrashes the TLB -- and the Gram is summed
+ * over the blocks in fp64.
+ * fp32 MFMA products, fp32 chains of at most 4096 rows, fp64 across chains.
  * Deterministic (no atomics).  */
 size_t dmdx_syrk_workspace_bytes(int64_t m, int64_t n);
 int dmdx_syrk_f32(const float* X, int64_t m, int64_t n, int64_t ldx,
-                  double* G64, int64_t ldg, float* G32, int64_t ldg32,
+                  double* G64, int64_t ldg, float* G32, int64_t ldg32, int accumulate,
                   void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- K3: C = A^T B, A: K x na, B: K x nb (both K-contiguous) ---------------
@@ -62,7 +67,7 @@ int dmdx_syrk_f32(const float* X, int64_t m, int64_t n, int64_t ldx,
 size_t dmdx_gemm_tn_workspace_bytes(int64_t K, int64_t na, int64_t nb);
 int dmdx_gemm_tn_f32(const float* A, int64_t lda, const float* B, int64_t ldb,
                      int64_t K, int64_t na, int64_t nb,
-                     double* C64, int64_t ldc, float* C32, int64_t ldc32,
+                     double* C64, int64_t ldc, float* C32, int64_t ldc32, int accumulate,
                      void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- K2: tall-skinny Y = X W -----------------------------------------------

@@ -12,13 +12,19 @@ import torch
 class CpuKernelDouble:
     name = "cpu-double"
 
-    def syrk(self, Xt, want32=False):
+    def syrk(self, Xt, want32=False, out=None):
         X = Xt.to(torch.float64)
         G = X @ X.T
+        if out is not None:
+            out += G
+            G = out
         return (G, G.float()) if want32 else G
 
-    def gemm_tn(self, At, Bt, want32=False):
+    def gemm_tn(self, At, Bt, want32=False, out=None):
         C = Bt.to(torch.float64) @ At.to(torch.float64).T
+        if out is not None:
+            out += C
+            C = out
         return (C, C.float()) if want32 else C
 
     def skinny(self, Xt, Wt):

@@ -249,3 +249,36 @@ def test_unsupported_type_raises_like_reference():
 
     with pytest.raises(ValueError, match="SVD type bogus is not supported."):
         svd_numpy(np.zeros((8, 4), dtype=np.float32), "bogus", 2)
+
+
+# ---------------------------------------------------------------- row blocks / accumulate
+def test_syrk_accumulates_over_row_blocks(K):
+    rs = np.random.RandomState(21)
+    X = _rand(rs, 3000, 150)
+    G = K.syrk(_dev(X[:1000].T))
+    K.syrk(_dev(X[1000:2200].T), out=G)
+    K.syrk(_dev(X[2200:].T), out=G)
+    ref = X.astype(np.float64).T @ X.astype(np.float64)
+    assert np.allclose(G.cpu().numpy(), ref, rtol=0, atol=2e-6 * np.abs(ref).max())
+    assert torch.equal(G, G.T)
+
+
+def test_blocked_svd_equals_unblocked(monkeypatch):
+    """The row-blocked HBM layout (svd.BLOCK_ROWS) must not change the result beyond
+    rounding (the fp32 chains are cut at different rows), for both svd types and with
+    delay embedding (which also checks the embedded row order of the assembled U)."""
+    from dmd_era5_amd import svd as dsvd
+    from dmd_era5_amd.engine import to_device_matrix
+
+    X = orc.lowrank_matrix(4096, 96, 40, 2)
+    Xt = to_device_matrix(X)
+    base = dsvd.svd_snapshots(Xt, 12, delay=2)
+    brand = dsvd.svd_randomized(Xt, 12, delay=2, random_state=0)
+    monkeypatch.setattr(dsvd, "BLOCK_ROWS", 500)
+    blk = dsvd.svd_snapshots(Xt, 12, delay=2)
+    assert blk.info["row_blocks"] > 1
+    assert torch.allclose(blk.s, base.s, rtol=1e-6)
+    assert torch.allclose(blk.Ut, base.Ut, atol=1e-5)
+    rr = dsvd.svd_randomized(Xt, 12, delay=2, random_state=0)
+    assert torch.allclose(rr.s, brand.s, rtol=1e-5)
+    assert torch.allclose(rr.Ut, brand.Ut, atol=1e-4)

@@ -1,0 +1,73 @@
+"""CPU tests of the C-ABI library: it loads without a GPU, exports exactly the
+symbols include/dmdx.h declares, and rejects bad arguments before touching HIP."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    so = os.path.join(ROOT, "dmd_era5_amd", "libdmdx.so")
+    if not os.path.exists(so):
+        import __graft_entry__
+
+        __graft_entry__.build()
+    from dmd_era5_amd import _lib
+
+    return _lib.load()
+
+
+def _header_symbols():
+    text = open(os.path.join(ROOT, "include", "dmdx.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(dmdx_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib):
+    from dmd_era5_amd import _lib
+
+    declared = _header_symbols()
+    assert len(declared) >= 10
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in dmdx.h but not exported"
+    assert sorted(_lib.SIGNATURES) == declared, "ctypes table and header disagree"
+
+
+def test_version_and_error_string(lib):
+    assert lib.dmdx_version() == 100
+    assert isinstance(lib.dmdx_last_error(), bytes)
+
+
+def test_argument_errors_are_reported_without_a_gpu(lib):
+    rc = lib.dmdx_syrk_f32(None, 10, 10, 10, None, 10, None, 10, 0, None, 0, None)
+    assert rc == -1000  # DMDX_E_INVALID
+    assert b"null" in lib.dmdx_last_error()
+    rc = lib.dmdx_gemm_nn_skinny_f32(None, 1, 1, 1, None, 1, 1, None, 1, None)
+    assert rc == -1000
+    rc = lib.dmdx_delay_shift_sum_f64(None, 4, 4, 2, None, 3, None, 0, None)
+    assert rc == -1000
+
+
+def test_workspace_queries(lib):
+    # 1 tile, >= 1 split; 128*128 doubles per partial tile
+    assert lib.dmdx_syrk_workspace_bytes(1000, 64) % (128 * 128 * 8) == 0
+    assert lib.dmdx_syrk_workspace_bytes(1000, 64) > 0
+    big = lib.dmdx_syrk_workspace_bytes(129780, 8760)
+    assert 0 < big < 8 << 30
+    assert lib.dmdx_gemm_tn_workspace_bytes(100000, 8760, 70) > 0
+
+
+def test_product_has_no_cpu_fallback():
+    """Without a GPU the kernel provider must refuse to construct."""
+    import torch
+
+    from dmd_era5_amd import _lib, kernels
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(_lib.DmdxError, match="no CPU fallback"):
+        kernels.HipKernels()

@@ -1,0 +1,148 @@
+"""CPU tests of the host-side algorithms (dmd_era5_amd.svd) with the kernel layer
+replaced by the CPU test double -- including the row-sharded multi-rank path over
+gloo with world_size 2."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from kernel_double import CpuKernelDouble
+from oracle import era5_oracle as orc
+from parity_utils import col_cosines, sv_tolerance
+
+from dmd_era5_amd import svd as dsvd
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+K = CpuKernelDouble()
+
+
+def _xt(X):
+    return torch.from_numpy(np.ascontiguousarray(X.T, dtype=np.float32))
+
+
+def test_snapshots_matches_golden():
+    g = np.load(os.path.join(GOLDEN, "lowrank_4096x192.npz"))
+    X = orc.lowrank_matrix(4096, 192, 100, 0)
+    for refine in (True, False):
+        r = dsvd.svd_snapshots(_xt(X), 50, refine=refine, kern=K)
+        assert np.all(np.abs(r.s.numpy() - g["s64"]) <= sv_tolerance(g["s64"]))
+        assert col_cosines(r.Ut.numpy().T, g["U64"]).min() > 1 - 1e-5
+        assert col_cosines(r.Vh.numpy().T, g["V64"].T).min() > 1 - 1e-5
+
+
+def test_top_eigh_krylov_equals_full():
+    rs = np.random.RandomState(0)
+    A = rs.standard_normal((3000, 400)) * (0.97 ** np.arange(400))
+    G = torch.from_numpy(A.T @ A)
+    info = {}
+    lam_k, V_k = dsvd.top_eigh(G, 20, method="krylov", info=info)
+    lam_f, V_f = dsvd.top_eigh(G, 20, method="full")
+    assert info["eig_method"] == "krylov"
+    assert torch.allclose(lam_k, lam_f, rtol=1e-10)
+    assert (V_k * V_f).sum(dim=0).abs().min() > 1 - 1e-8
+
+
+def test_randomized_same_omega_as_sklearn():
+    g = np.load(os.path.join(GOLDEN, "lowrank_4096x192.npz"))
+    X = orc.lowrank_matrix(4096, 192, 100, 0)
+    r = dsvd.svd_randomized(_xt(X), 50, random_state=0, kern=K)
+    assert r.info["n_iter"] == 4 and r.info["l"] == 60
+    assert np.allclose(r.s.numpy(), g["rdef_s"], rtol=2e-5)
+    assert np.all(np.sum(r.Ut.numpy().T * g["rdef_U"], axis=0) > 0.9999)
+    r2 = dsvd.svd_randomized(_xt(X), 50, omega=g["rdef_omega"].astype(np.float64), kern=K)
+    assert torch.allclose(r2.s, r.s, rtol=1e-6)
+
+
+def test_n_iter_auto_rule():
+    assert dsvd.resolve_n_iter(10, 5184, 24) == 4      # k >= 0.1 * min(m, n)
+    assert dsvd.resolve_n_iter(50, 1038240, 8760) == 7
+    assert dsvd.resolve_n_iter(50, 100, 100, n_iter=2) == 2
+
+
+@pytest.mark.parametrize("d", [2, 3])
+def test_delay_embedding_paths(d):
+    X = orc.lowrank_matrix(1500, 60, 30, 4)
+    Xe = orc.delay_embed(X, d)
+    Ue, se, Ve = orc.svd_standard(Xe.astype(np.float64), 8)
+    Ue, Ve = orc.svd_flip(Ue, Ve)
+    r = dsvd.svd_snapshots(_xt(X), 8, delay=d, kern=K)
+    assert r.Ut.shape == (8, d * 1500) and r.Vh.shape == (8, 60 - d + 1)
+    assert np.allclose(r.s.numpy(), se, rtol=1e-6)
+    assert np.all(np.sum(r.Ut.numpy().T * Ue, axis=0) > 0.9999)   # row order k*m + s
+    assert torch.equal(dsvd.embed_view(_xt(X), d), torch.from_numpy(np.ascontiguousarray(Xe.T)))
+
+
+def test_row_blocks_do_not_change_the_answer(monkeypatch):
+    X = orc.lowrank_matrix(4096, 96, 40, 2)
+    base = dsvd.svd_snapshots(_xt(X), 12, delay=2, kern=K)
+    monkeypatch.setattr(dsvd, "BLOCK_ROWS", 500)
+    blk = dsvd.svd_snapshots(_xt(X), 12, delay=2, kern=K)
+    assert blk.info["row_blocks"] == 9
+    assert torch.allclose(blk.s, base.s, rtol=1e-10)
+    assert torch.allclose(blk.Ut, base.Ut, atol=1e-6)
+    assert dsvd.split_rows(1038240, 131072) == [(i * 129780, (i + 1) * 129780) for i in range(8)]
+
+
+def test_rank_deficient_input_gives_zero_tail():
+    rs = np.random.RandomState(1)
+    X = (rs.standard_normal((500, 3)) @ rs.standard_normal((3, 40))).astype(np.float32)
+    r = dsvd.svd_snapshots(_xt(X), 6, kern=K)
+    s = r.s.numpy()
+    assert np.all(s[:3] > 1) and np.all(s[3:] < 1e-3 * s[0])
+    assert np.isfinite(r.Ut.numpy()).all()
+
+
+# ---------------------------------------------------------------- world_size 2 over gloo
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, svd_type, q):
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        X = orc.lowrank_matrix(3000, 96, 40, 2)
+        rows = np.array_split(np.arange(3000), world)[rank]
+        comm = dsvd.TorchDistComm()
+        Xt = _xt(X[rows])
+        if svd_type == "standard":
+            r = dsvd.svd_snapshots(Xt, 10, comm=comm, kern=K)
+        else:
+            r = dsvd.svd_randomized(Xt, 10, random_state=0, comm=comm, kern=K)
+        q.put((rank, r.s.numpy(), r.Ut.numpy(), r.Vh.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("svd_type", ["standard", "randomized"])
+def test_row_sharded_two_ranks_equal_single_rank(svd_type):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, svd_type, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    X = orc.lowrank_matrix(3000, 96, 40, 2)
+    if svd_type == "standard":
+        ref = dsvd.svd_snapshots(_xt(X), 10, kern=K)
+    else:
+        ref = dsvd.svd_randomized(_xt(X), 10, random_state=0, kern=K)
+    U = np.concatenate([o[2] for o in out], axis=1)            # shards are contiguous row ranges
+    assert np.allclose(out[0][1], out[1][1])                   # s replicated
+    assert np.allclose(out[0][1], ref.s.numpy(), rtol=1e-8)
+    assert np.allclose(out[0][3], ref.Vh.numpy(), atol=1e-7)
+    assert np.allclose(U, ref.Ut.numpy(), atol=1e-6)           # includes the global sign flip

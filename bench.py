@@ -182,6 +182,19 @@ def main():
     flops = float(m) * n * (n + 1) / nblk                  # algorithmic flops of that launch
     achieved = flops / (syrk_ms * 1e-3) / 1e12
 
+    # HBM-side traffic of the Gram kernel: PMC numbers cannot be collected from inside this
+    # process; they come from the committed rocprofv3 --pmc passes of this same command
+    # (profiles/r1_bench_rocprof_summary.json: FETCH_SIZE doubled per the gfx950 note of
+    # MI355X_MICROARCH.md, plus WRITE_SIZE, per launch).
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r1_bench_rocprof_summary.json")) as f:
+            prof = json.load(f)
+        if args.workload == "cfg2":
+            traffic = float(prof["traffic"]["bytes_per_launch_corrected"])
+    except Exception:
+        traffic = None
+
     out = {
         "metric": "rank-r SVD GB/s on ERA5 snapshot matrix (X resident in HBM)",
         "value": world * m * n * 4.0 * args.steps / dt / 1e9,
@@ -207,7 +220,8 @@ def main():
             "peak": PEAK_FP32_MFMA_TFLOPS,
             "unit": "TFLOP/s",
             "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
-            "traffic": None,
+            "traffic": traffic,
+            "traffic_unit": "bytes/launch (L2<->fabric, PMC; profiles/r1_bench_rocprof_summary.json)",
             "flops_per_launch": flops,
             "ms_per_launch": syrk_ms,
         },

@@ -1,0 +1,95 @@
+"""GPU end-to-end tests of the drop-in entry points: ``main`` (device pipeline: upload ->
+K5 centre/scale -> zero-copy delay view -> SVD -> NetCDF) and ``svd_on_era5`` against the
+CPU oracle restating the reference's stages on the same seeded mock slice."""
+import numpy as np
+import pytest
+
+from oracle import era5_oracle as orc
+from parity_utils import col_cosines
+
+pytestmark = pytest.mark.gpu
+
+
+def _write_slice(cfg, seed, dtype):
+    from dmd_era5_amd import io_netcdf
+    from dmd_era5_amd.config_parser import config_parser
+    from dmd_era5_amd.create_mock_data import add_download_attributes, create_mock_era5
+
+    p = config_parser(cfg, "era5-svd")
+    ds = add_download_attributes(
+        create_mock_era5(cfg["start_datetime"], cfg["end_datetime"], p["variables"], p["levels"],
+                         seed=seed, dtype=dtype), p)
+    io_netcdf.to_netcdf(ds, p["era5_slice_path"])
+    return p, ds
+
+
+@pytest.mark.parametrize("svd_type,scale,d", [("standard", False, 2), ("standard", True, 1),
+                                              ("randomized", False, 2), ("standard", True, 3)])
+def test_main_matches_oracle_pipeline(svd_base_config, project_root, svd_type, scale, d):
+    from dmd_era5_amd.era5_svd import main
+
+    cfg = dict(svd_base_config, start_datetime="2019-01-01T00", end_datetime="2019-01-03T00",
+               variables="temperature,u_component_of_wind", levels="1000,850", svd_type=svd_type,
+               mean_center=True, scale=scale, delay_embedding=d, n_components=6,
+               save_data_matrix=True, svd_seed=0)
+    p, ds = _write_slice(cfg, seed=3, dtype=np.float32)
+    res, added, retrieved = main(cfg, write_to_netcdf=True)
+    assert (added, retrieved) == (False, False)
+
+    variables = {k: ds[k].values for k in p["variables"]}
+    X, X_mean, X_std = orc.preprocess(variables, True, scale, d)
+    Uo, so, Vo = orc.svd_standard(X.astype(np.float64), 6)
+    m = X.shape[0]
+    assert res["U"].shape == (m, 6) and res["V"].shape == (6, X.shape[1]) and res["s"].shape == (6,)
+    assert res["U"].values.dtype == np.float32
+    # the pre-processed matrix itself (K5 + embedding order) against the reference arithmetic
+    assert np.allclose(res["X"].values, X, rtol=0, atol=2e-4 * (1 if scale else 30))
+    # mock data are white noise beyond the first (mean-structure) components: singular values
+    # cluster, so compare s tightly and the subspace via the reconstruction
+    rtol = 2e-5 if svd_type == "standard" else 2e-2
+    assert np.allclose(res["s"].values, so, rtol=rtol)
+    if svd_type == "standard":
+        rec = (res["U"].values.astype(np.float64) * res["s"].values) @ res["V"].values
+        ref = (Uo * so) @ Vo
+        assert np.linalg.norm(rec - ref) <= 2e-3 * np.linalg.norm(ref)
+    U = res["U"].values.astype(np.float64)
+    assert np.abs(U.T @ U - np.eye(6)).max() < 1e-4
+    # labels and the X_mean quirk (kept only when centred and d > 1, ref era5_svd.py:400-414)
+    assert np.array_equal(res.coords["delay"].values, orc.delay_labels(m // d, d))
+    assert np.array_equal(res.coords["space"].values, np.arange(m))
+    assert list(res.coords["original_variable"].values[[0, m // d - 1]]) == ["temperature", "u_component_of_wind"]
+    if d > 1:
+        assert np.allclose(res["X_mean"].values, X_mean, rtol=1e-6)
+        if scale:
+            assert np.allclose(res["X_std"].values, X_std, rtol=1e-5)
+    else:
+        assert "X_mean" not in res
+    assert res.attrs["svd_type"] == svd_type and res.attrs["delay_embedding"] == d
+    # second call: the stored result is returned (ref era5_svd.py:203-208)
+    again, _, _ = main(cfg, write_to_netcdf=True)
+    assert np.allclose(again["s"].values, res["s"].values)
+    assert again["U"].shape == res["U"].shape
+
+
+@pytest.mark.parametrize("svd_type", ["standard", "randomized"])
+def test_svd_on_era5_shapes_like_reference_test(svd_base_config, svd_type):
+    """reference tests/test_03_era5_svd.py:153-176 (shapes), plus orthonormality."""
+    from dmd_era5_amd import slice_tools as st
+    from dmd_era5_amd.config_parser import config_parser
+    from dmd_era5_amd.create_mock_data import create_mock_era5
+    from dmd_era5_amd.era5_svd import svd_on_era5
+
+    cfg = dict(svd_base_config, svd_type=svd_type)
+    p = config_parser(cfg, "era5-svd")
+    data = create_mock_era5("2019-01-01", "2019-01-02", ["temperature"], [1000], seed=9)
+    da = st.apply_delay_embedding(st.flatten_era5_variables(data), p["delay_embedding"])
+    U, s, V = svd_on_era5(da, p)
+    n_samples, n_time = da.shape
+    assert U.shape == (n_samples, 10) and s.shape == (10,) and V.shape == (10, n_time)
+    assert U.dtype == np.float64                     # fp64 in -> fp64 out (fp32 arithmetic)
+    assert np.all(np.diff(s) <= 1e-6 * s[0])
+    Ur, sr, Vr = orc.svd_standard(da.values, 10)
+    assert np.allclose(s[:1], sr[:1], rtol=1e-5)     # un-centred mock: one dominant component
+    assert col_cosines(U[:, :1], Ur[:, :1]).min() > 1 - 1e-6
+    with pytest.raises(ValueError, match="SVD type foo is not supported."):
+        svd_on_era5(da, dict(p, svd_type="foo"))

@@ -1,0 +1,241 @@
+"""CPU tests of the mirrored reference interface (config, slice tools, result packaging,
+NetCDF round trip).  Each test states the reference test whose behaviour it re-checks
+(/root/reference/tests/...); data come from the seeded mock generator."""
+import os
+from datetime import datetime, timedelta
+
+import numpy as np
+import pytest
+
+from dmd_era5_amd import io_netcdf, slice_tools as st
+from dmd_era5_amd.config_parser import config_parser
+from dmd_era5_amd.config_reader import config_reader
+from dmd_era5_amd.create_mock_data import add_download_attributes, create_mock_era5
+from dmd_era5_amd.labeled import DataArray, Dataset
+
+
+# ---- config parser: reference tests/test_00_config_parser.py, test_03_era5_svd.py:71-150
+def test_config_parser_basic(svd_base_config, project_root):
+    p = config_parser(svd_base_config, section="era5-svd")
+    assert p["start_datetime"] == datetime(2019, 1, 1, 6, 0)
+    assert p["end_datetime"] == datetime(2020, 1, 1, 12, 0)
+    assert p["delta_time"] == timedelta(hours=1)
+    assert p["save_name"] == "2019-01-01T06_2020-01-01T12_1h.nc"
+    assert p["save_path"] == os.path.join(str(project_root), "data", "era5_svd", p["save_name"])
+    assert p["era5_slice_path"] == os.path.join(str(project_root), "data", "era5_download", p["save_name"])
+    assert p["era5_svd_path"] == p["save_path"]
+    assert p["variables"] == ["temperature"] and p["levels"] == [1000]
+
+
+@pytest.mark.parametrize("field", ["source_path", "variables", "levels", "svd_type", "delay_embedding",
+                                   "mean_center", "scale", "start_datetime", "end_datetime",
+                                   "delta_time", "n_components", "save_data_matrix"])
+def test_config_parser_missing_field(svd_base_config, field):
+    del svd_base_config[field]
+    with pytest.raises(ValueError, match=f"Missing required field in config: {field}"):
+        config_parser(svd_base_config, section="era5-svd")
+
+
+def test_config_parser_invalid_values(svd_base_config):
+    for key, bad, msg in [("svd_type", "invalid", "Invalid SVD type in config"),
+                          ("delay_embedding", 0, "Invalid delay embedding in config"),
+                          ("delay_embedding", 1.2, "Invalid delay embedding in config"),
+                          ("delay_embedding", "invalid", "Invalid delay embedding in config"),
+                          ("n_components", 0, "Invalid number of components in config"),
+                          ("n_components", 1.2, "Invalid number of components in config"),
+                          ("n_components", "invalid", "Invalid number of components in config"),
+                          ("start_datetime", "2019-13-01", "Invalid datetime"),
+                          ("delta_time", "1x", "Error parsing delta_time"),
+                          ("delta_time", "h", "Error parsing delta_time"),
+                          ("variables", "2m_temperature", "Single level variables not currently supported"),
+                          ("levels", "999", "Unsupported level in config")]:
+        cfg = dict(svd_base_config)
+        cfg[key] = bad
+        with pytest.raises(ValueError, match=msg):
+            config_parser(cfg, section="era5-svd")
+    with pytest.raises(ValueError, match="is not currently supported"):
+        config_parser(svd_base_config, section="nope")
+
+
+@pytest.mark.parametrize("text,expected", [("1h", timedelta(hours=1)), ("24h", timedelta(hours=24)),
+                                           ("1d", timedelta(days=1)), ("7d", timedelta(days=7)),
+                                           ("2w", timedelta(weeks=2)), ("1m", timedelta(days=30)),
+                                           ("1y", timedelta(days=365))])
+def test_delta_time_units(svd_base_config, text, expected):
+    cfg = dict(svd_base_config, delta_time=text)
+    assert config_parser(cfg, "era5-svd")["delta_time"] == expected
+
+
+def test_time_validation(svd_base_config):
+    with pytest.raises(ValueError, match="End datetime must be after start datetime"):
+        config_parser(dict(svd_base_config, end_datetime="2019-01-01T06"), "era5-svd")
+    with pytest.raises(ValueError, match="Time range must be at least as long as delta_time"):
+        config_parser(dict(svd_base_config, end_datetime="2019-01-01T07", delta_time="1d"), "era5-svd")
+    with pytest.raises(ValueError, match="Start date cannot be in the future"):
+        config_parser(dict(svd_base_config, start_datetime="2999-01-01T00", end_datetime="2999-02-01T00"),
+                      "era5-svd")
+
+
+# ---- config reader: reference tests/test_00_config_reader.py
+def test_config_reader_types_and_errors(tmp_path):
+    ini = tmp_path / "config.ini"
+    ini.write_text('[test-section-0]\nparam_0 = "value_0"\nparam_2 = "a,b"\n\n'
+                   '[test-section-1]\nparam_3 = True\nparam_4 = 2\nparam_5 = 1.5\n')
+    c0 = config_reader("test-section-0", str(ini))
+    assert c0 == {"param_0": "value_0", "param_2": "a,b"}
+    c1 = config_reader("test-section-1", str(ini))
+    assert c1["param_3"] is True and c1["param_4"] == 2 and isinstance(c1["param_5"], float)
+    with pytest.raises(Exception, match="Section nope not found"):
+        config_reader("nope", str(ini))
+    (tmp_path / "bad.ini").write_text("[s]\nx = not a literal\n")
+    with pytest.raises((ValueError, SyntaxError)):
+        config_reader("s", str(tmp_path / "bad.ini"))
+
+
+def test_shipped_config_ini_has_the_reference_keys():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = config_reader("era5-svd", os.path.join(root, "config.ini"))
+    assert set(cfg) >= {"source_path", "start_datetime", "end_datetime", "delta_time", "variables", "levels",
+                        "svd_type", "delay_embedding", "mean_center", "scale", "n_components",
+                        "save_data_matrix"}
+    assert isinstance(cfg["delay_embedding"], int) and isinstance(cfg["mean_center"], bool)
+    dl = config_reader("era5-download", os.path.join(root, "config.ini"))
+    assert set(dl) == {"source_path", "start_datetime", "end_datetime", "delta_time", "variables", "levels"}
+
+
+# ---- slice tools: reference tests/test_02_slice_tools.py
+@pytest.fixture
+def mock_tw():
+    return create_mock_era5("2019-01-01", "2019-01-02", ["temperature", "u_component_of_wind"], [1000, 850],
+                            seed=11)
+
+
+def test_slice_time_and_levels(mock_tw):
+    s = st.slice_era5_dataset(mock_tw, "2019-01-01T06", "2019-01-01T12", levels=[850])
+    assert s.sizes["time"] == 7 and list(s.coords["level"].values) == [850]
+    s = st.slice_era5_dataset(mock_tw, levels=[850, 1000])
+    assert list(s.coords["level"].values) == [850, 1000]        # requested order
+    assert np.array_equal(s["temperature"].values[:, 0], mock_tw["temperature"].values[:, 1])
+    with pytest.raises(ValueError, match="outside dataset"):
+        st.slice_era5_dataset(mock_tw, "2018-12-31T00", "2019-01-01T12")
+    with pytest.raises(ValueError, match="Start datetime must be before end datetime"):
+        st.slice_era5_dataset(mock_tw, "2019-01-01T12", "2019-01-01T06")
+    with pytest.raises(ValueError, match="Requested level is not available"):
+        st.slice_era5_dataset(mock_tw, levels=[500])
+
+
+def test_resample_nearest_6h(mock_tw):
+    r = st.resample_era5_dataset(mock_tw, timedelta(hours=6))
+    assert r.sizes["time"] == 5, "Expected 5 time points"
+    dt = np.diff(r.coords["time"].values).astype("timedelta64[h]").astype(int)
+    assert np.all(dt == 6)
+    assert np.array_equal(r["temperature"].values[1], mock_tw["temperature"].values[6])
+    same = st.resample_era5_dataset(mock_tw, timedelta(hours=1))
+    assert same.sizes["time"] == 25
+
+
+def test_standardize_and_flatten_and_embed(mock_tw):
+    c, mu, sd = st.standardize_data(mock_tw)
+    assert np.allclose(c["temperature"].values.mean(axis=0), 0, atol=1e-6)
+    assert np.allclose(c["u_component_of_wind"].values.std(axis=0), 1, atol=1e-6)
+    c2, _, none = st.standardize_data(mock_tw, scale=False)
+    assert none is None and not np.allclose(c2["temperature"].values.std(axis=0), 1, atol=1e-6)
+    da = st.flatten_era5_variables(mock_tw)
+    n_space = 2 * 36 * 72
+    assert da.shape == (2 * n_space, 25) and da.dims == ("space", "time")
+    assert sorted(da.coords) == ["original_variable", "space", "time"]
+    assert da.attrs["original_variables"] == ["temperature", "u_component_of_wind"]
+    lats, lons = mock_tw.coords["latitude"].values, mock_tw.coords["longitude"].values
+    for level, lat, lon in [(1000, 40, 90), (1000, -20, -50), (850, 0, 0)]:
+        rows = np.nonzero((da.coords["space"].values == [level, lat, lon]).all(axis=1))[0]
+        assert len(rows) == 2
+        li = [1000, 850].index(level)
+        i, j = int(np.where(lats == lat)[0][0]), int(np.where(lons == lon)[0][0])
+        assert np.allclose(da.values[rows[0]], mock_tw["temperature"].values[:, li, i, j])
+        assert np.allclose(da.values[rows[1]], mock_tw["u_component_of_wind"].values[:, li, i, j])
+    flat_mean = st.flatten_era5_variables(mu)
+    assert flat_mean.dims == ("space",) and flat_mean.shape == (2 * n_space,)
+    for d in (2, 3):
+        e = st.apply_delay_embedding(da, d)
+        assert e.shape == (da.shape[0] * d, da.shape[1] - d + 1)
+        assert sorted(e.coords) == ["delay", "original_variable", "space", "time"]
+        assert np.array_equal(np.unique(e.coords["delay"].values), np.arange(d))
+        assert np.array_equal(e.coords["time"].values, da.coords["time"].values[d - 1:])
+        m = da.shape[0]
+        for k in range(d):                       # block k carries delay d-1-k and X[:, k:k+nt]
+            assert np.all(e.coords["delay"].values[k * m:(k + 1) * m] == d - 1 - k)
+            assert np.array_equal(e.values[k * m:(k + 1) * m], da.values[:, k:k + e.shape[1]])
+    with pytest.raises(ValueError, match="Input data must be a xr.DataArray"):
+        st.apply_delay_embedding(da.values, 2)
+
+
+def test_space_coord_to_level_lat_lon(mock_tw):
+    da = st.flatten_era5_variables(mock_tw[["temperature"]])
+    ds = Dataset({"temperature": da})
+    sp = da.coords["space"].values.copy()
+    out = st.space_coord_to_level_lat_lon(ds)
+    assert np.array_equal(out.coords["space"].values, np.arange(len(sp)))
+    assert (sp[0] == [out.coords["level"].values[0], out.coords["latitude"].values[0],
+                      out.coords["longitude"].values[0]]).all()
+    assert (sp[-1] == [out.coords["level"].values[-1], out.coords["latitude"].values[-1],
+                       out.coords["longitude"].values[-1]]).all()
+    assert st.space_coord_to_level_lat_lon(out) is out    # second call is a no-op
+
+
+# ---- result packaging + NetCDF round trip: reference tests/test_03_era5_svd.py:179-235
+def test_combine_and_roundtrip(svd_base_config, project_root):
+    from dmd_era5_amd.era5_svd import (add_config_attributes, combine_svd_results,
+                                       retrieve_era5_slice, retrieve_svd_results)
+
+    p = config_parser(dict(svd_base_config, start_datetime="2019-01-01T00", end_datetime="2019-01-02T00",
+                           n_components=6), "era5-svd")
+    assert retrieve_era5_slice(p, use_dvc=False) == (None, False)       # nothing on disk yet
+    assert retrieve_svd_results(p) == (None, False)
+    ds = create_mock_era5("2019-01-01", "2019-01-02", ["temperature"], [1000], seed=5)
+    c, mu, _ = st.standardize_data(ds, scale=False)
+    da = st.apply_delay_embedding(st.flatten_era5_variables(c), 2)
+    U, s, V = np.linalg.svd(da.values, full_matrices=False)             # packaging only
+    U, s, V = U[:, :6], s[:6], V[:6]
+    res = combine_svd_results(U, s, V, da.coords, X=da)
+    assert sorted(res.data_vars) == ["U", "V", "X", "s"]
+    assert res["U"].dims == ("space", "components") and res["V"].dims == ("components", "time")
+    assert sorted(res["U"].coords) == ["components", "delay", "original_variable", "space"]
+    assert sorted(res["s"].coords) == ["components"] and sorted(res["V"].coords) == ["components", "time"]
+    res = st.space_coord_to_level_lat_lon(add_config_attributes(res, p))
+    assert res.attrs["mean_center"] == 0 and res.attrs["svd_type"] == "randomized"
+    io_netcdf.to_netcdf(res, p["save_path"])
+    back, _ = retrieve_svd_results(p)                                   # cache hit on matching attrs
+    assert back is not None
+    assert np.allclose(back["U"].values, U) and np.allclose(back["s"].values, s)
+    assert back["X"].shape == da.shape
+    assert list(np.unique(back.coords["original_variable"].values)) == ["temperature"]
+    assert np.array_equal(back.coords["time"].values, da.coords["time"].values)
+    other = config_parser(dict(svd_base_config, start_datetime="2019-01-01T00",
+                               end_datetime="2019-01-02T00", n_components=7), "era5-svd")
+    assert retrieve_svd_results(other) == (None, False)                 # attrs differ -> no hit
+
+
+def test_era5_slice_roundtrip_and_match(svd_base_config, project_root):
+    from dmd_era5_amd.era5_svd import retrieve_era5_slice
+
+    cfg = dict(svd_base_config, start_datetime="2019-01-01T00", end_datetime="2019-01-02T00",
+               variables="temperature,u_component_of_wind", levels="1000,850")
+    p = config_parser(cfg, "era5-svd")
+    ds = add_download_attributes(
+        create_mock_era5("2019-01-01", "2019-01-02", p["variables"], p["levels"], seed=2, dtype=np.float32), p)
+    io_netcdf.to_netcdf(ds, p["era5_slice_path"])
+    got, _ = retrieve_era5_slice(p)
+    assert got is not None and np.array_equal(got["temperature"].values, ds["temperature"].values)
+    sub = config_parser(dict(cfg, variables="temperature", levels="850"), "era5-svd")
+    assert retrieve_era5_slice(sub)[0] is not None                      # subset of the file -> accepted
+    wrong = config_parser(dict(cfg, variables="v_component_of_wind"), "era5-svd")
+    assert retrieve_era5_slice(wrong)[0] is None
+    with pytest.raises(NotImplementedError):
+        retrieve_era5_slice(p, use_dvc=True)
+
+
+def test_main_reports_missing_slice_like_the_reference(svd_base_config, project_root):
+    from dmd_era5_amd.era5_svd import main
+
+    with pytest.raises(Exception, match="Error retrieving ERA5 slice"):
+        main(svd_base_config)

@@ -46,8 +46,15 @@ def test_main_matches_oracle_pipeline(svd_base_config, project_root, svd_type, s
     assert np.allclose(res["X"].values, X, rtol=0, atol=2e-4 * (1 if scale else 30))
     # mock data are white noise beyond the first (mean-structure) components: singular values
     # cluster, so compare s tightly and the subspace via the reconstruction
-    rtol = 2e-5 if svd_type == "standard" else 2e-2
-    assert np.allclose(res["s"].values, so, rtol=rtol)
+    if svd_type == "standard":
+        assert np.allclose(res["s"].values, so, rtol=2e-5)
+    else:
+        # flat (white-noise) spectrum: the randomized estimate is 1-3 % below the exact values
+        # by construction, so compare with the reference algorithm
+        # (oracle restatement of sklearn) run on the same Omega = RandomState(0) draw
+        Ur, sr, Vr = orc.svd_randomized(X, 6, random_state=0)
+        assert np.allclose(res["s"].values, sr, rtol=1e-3)
+        assert np.all(res["s"].values <= so * (1 + 1e-5)) and np.all(res["s"].values >= 0.95 * so)
     if svd_type == "standard":
         rec = (res["U"].values.astype(np.float64) * res["s"].values) @ res["V"].values
         ref = (Uo * so) @ Vo
@@ -59,7 +66,9 @@ def test_main_matches_oracle_pipeline(svd_base_config, project_root, svd_type, s
     assert np.array_equal(res.coords["space"].values, np.arange(m))
     assert list(res.coords["original_variable"].values[[0, m // d - 1]]) == ["temperature", "u_component_of_wind"]
     if d > 1:
-        assert np.allclose(res["X_mean"].values, X_mean, rtol=1e-6)
+        # the reference's mean is an fp32 accumulation (numpy), ours fp64 rounded once:
+        # they agree to the fp32 summation error of n ~ 49 values of size <= 280
+        assert np.allclose(res["X_mean"].values, X_mean, rtol=1e-5, atol=2e-4)
         if scale:
             assert np.allclose(res["X_std"].values, X_std, rtol=1e-5)
     else:

@@ -123,8 +123,11 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
         args.gpus = world
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # DMDX_BENCH_DEVICE / DMDX_DIST_BACKEND: rehearsal knobs (several ranks on ONE GPU over gloo,
+    # to exercise the N > 1 code path on a single-GPU box); the driver's runs use neither.
+    dev_index = int(os.environ.get("DMDX_BENCH_DEVICE", local_rank))
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
 
     from dmd_era5_amd import svd as dsvd
     from dmd_era5_amd.kernels import default_kernels
@@ -134,7 +137,11 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        backend = os.environ.get("DMDX_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
         comm = dsvd.TorchDistComm()
     else:
         dist = None

@@ -113,6 +113,20 @@ __global__ __launch_bounds__(256, (C <= 2 ? 2 : 1)) void skinny_kernel(
   for (int s = 0; s < 8; ++s) xa[s] = load_x(2 * s);
   __syncthreads();
 
+  // One k-step = 4*C MFMAs on one X register quad and C values of W.  The W values of
+  // step s+1 are read from LDS before the MFMAs of step s are issued (bn), so the LDS
+  // latency is covered by the 4*C*64 matrix-pipe cycles of the step.
+#define DMDX_READ_B(dst, s_)                                                         \
+  do {                                                                               \
+    _Pragma("unroll") for (int cc = 0; cc < C; ++cc) dst[cc] = ws[32 * cc * LDW + 2 * (s_)]; \
+  } while (0)
+#define DMDX_STEP(xreg, bv)                                                          \
+  do {                                                                               \
+    _Pragma("unroll") for (int e = 0; e < 4; ++e)                                    \
+        _Pragma("unroll") for (int cc = 0; cc < C; ++cc) acc[e][cc] =                \
+            __builtin_amdgcn_mfma_f32_32x32x2f32(xreg[e], bv[cc], acc[e][cc], 0, 0, 0); \
+  } while (0)
+
   int cur = 0;
   for (int c = 0; c < nchunks; ++c) {
     const int64_t k0 = (int64_t)c * KB;
@@ -122,36 +136,42 @@ __global__ __launch_bounds__(256, (C <= 2 ? 2 : 1)) void skinny_kernel(
     if (has_next) load_w(k0 + KB);
 
     const float* ws = &Ws[cur][l31 * LDW + lh];
+    float b0[C], b1[C];
+    DMDX_READ_B(b0, 0);
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      float b[C];
-#pragma unroll
-      for (int cc = 0; cc < C; ++cc) b[cc] = ws[32 * cc * LDW + 2 * s];
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-#pragma unroll
-        for (int cc = 0; cc < C; ++cc)
-          acc[e][cc] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[s][e], b[cc], acc[e][cc], 0, 0, 0);
+    for (int s = 0; s < 8; s += 2) {
+      DMDX_READ_B(b1, s + 1);
+      __builtin_amdgcn_sched_group_barrier(0x100, (C + 1) / 2, 0);
+      DMDX_STEP(xa[s], b0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4 * C, 0);
+      DMDX_READ_B(b0, s + 2);  // s + 2 == 8 is the first step of the second half
+      __builtin_amdgcn_sched_group_barrier(0x100, (C + 1) / 2, 0);
+      DMDX_STEP(xa[s + 1], b1);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4 * C, 0);
     }
     if (has_next) {
 #pragma unroll
       for (int s = 0; s < 8; ++s) xa[s] = load_x(k0 + KB + 2 * s);
     }
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      float b[C];
-#pragma unroll
-      for (int cc = 0; cc < C; ++cc) b[cc] = ws[32 * cc * LDW + 16 + 2 * s];
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-#pragma unroll
-        for (int cc = 0; cc < C; ++cc)
-          acc[e][cc] = __builtin_amdgcn_mfma_f32_32x32x2f32(xb[s][e], b[cc], acc[e][cc], 0, 0, 0);
+    for (int s = 0; s < 8; s += 2) {
+      DMDX_READ_B(b1, 8 + s + 1);
+      __builtin_amdgcn_sched_group_barrier(0x100, (C + 1) / 2, 0);
+      DMDX_STEP(xb[s], b0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4 * C, 0);
+      if (s + 2 < 8) {
+        DMDX_READ_B(b0, 8 + s + 2);
+        __builtin_amdgcn_sched_group_barrier(0x100, (C + 1) / 2, 0);
+      }
+      DMDX_STEP(xb[s + 1], b1);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4 * C, 0);
     }
     if (has_next) store_w(cur ^ 1);
     __syncthreads();
     cur ^= 1;
   }
+#undef DMDX_READ_B
+#undef DMDX_STEP
 
   // ---- epilogue: lane (j = l31, h) holds, for register r, MFMA row
   // i_m = (r&3) + 8*(r>>2) + 4*h of each row-block e  ->  global rows

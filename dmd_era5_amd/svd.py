@@ -61,6 +61,12 @@ class Comm:
     def allgather(self, t: torch.Tensor) -> list[torch.Tensor]:
         return [t]
 
+    def broadcast_(self, *tensors: torch.Tensor):
+        """Make rank 0's copy of small replicated results (eigenvectors, rotations)
+        authoritative: every rank computes them from identical all-reduced inputs, but a
+        last-bit or sign difference between devices would make the U shards inconsistent."""
+        return tensors if len(tensors) != 1 else tensors[0]
+
 
 class TorchDistComm(Comm):
     """torch.distributed communicator: backend "nccl" is RCCL over xGMI on ROCm;
@@ -85,6 +91,12 @@ class TorchDistComm(Comm):
         out = [torch.empty_like(t) for _ in range(self.world_size)]
         self._dist.all_gather(out, t.contiguous(), group=self._group)
         return out
+
+    def broadcast_(self, *tensors: torch.Tensor):
+        if self.world_size > 1:
+            for t in tensors:
+                self._dist.broadcast(t, src=0, group=self._group)
+        return tensors if len(tensors) != 1 else tensors[0]
 
 
 @dataclass
@@ -304,6 +316,7 @@ def svd_snapshots(Xt, n_components: int, delay: int = 1, oversample: int | None 
     p = oversample if oversample is not None else max(8, k // 4)
     l = min(nd, k + p) if refine else k
     lam, V = top_eigh(G, l, method=eig_method, info=info)
+    comm.broadcast_(lam, V)
     lam1 = lam[0].clamp_min(1e-300)
     good = lam > lam1 * 1e-14
     s0 = torch.sqrt(torch.where(good, lam, torch.ones_like(lam)))
@@ -322,8 +335,9 @@ def svd_snapshots(Xt, n_components: int, delay: int = 1, oversample: int | None 
         T = s0[:, None] * Mm * s0[None, :]
         T = 0.5 * (T + T.T)
         mu, Z = torch.linalg.eigh(T)
-        mu = torch.flip(mu, dims=(0,))[:k]
-        Z = torch.flip(Z, dims=(1,))[:, :k]
+        mu = torch.flip(mu, dims=(0,))[:k].contiguous()
+        Z = torch.flip(Z, dims=(1,))[:, :k].contiguous()
+        comm.broadcast_(mu, Z)
         s = torch.sqrt(mu.clamp_min(0.0))
         ok = s > s0[0] * 1e-7
         inv_s = torch.where(ok, 1.0 / torch.where(ok, s, torch.ones_like(s)), torch.zeros_like(s))
@@ -363,7 +377,7 @@ def _cholqr(Yb, comm: Comm, kern, passes: int = 1):
             shift = 1e-12 * torch.diagonal(G).sum()
             L = torch.linalg.cholesky(G + shift * eye)
         Rinv = torch.linalg.solve_triangular(L.T, eye, upper=True)  # R = L^T
-        Rt = Rinv.T.contiguous().to(torch.float32)
+        Rt = comm.broadcast_(Rinv.T.contiguous().to(torch.float32))
         Yb = [kern.skinny(Y, Rt) for Y in Yb]
     return Yb
 
@@ -435,10 +449,13 @@ def svd_randomized(Xt, n_components: int, delay: int = 1, n_oversamples: int = 1
             Qt = _orth(Zt.T).T.contiguous().to(torch.float32)
         else:
             Qt = Zt.to(torch.float32)
+        comm.broadcast_(Qt)
     Yb = [kern.skinny(E, Qt) for E in Eb]        # extmath.py:355
     Qmb = _cholqr(Yb, comm, kern, passes=2)      # orthonormal basis of range(Y)
     Bm = _gemm_tn_blocks(Eb, Qmb, kern, comm)    # (l, nd) = Q^T X    (extmath.py:577)
     Uhat, s, Vh = torch.linalg.svd(Bm, full_matrices=False)
+    Uhat, s, Vh = Uhat.contiguous(), s.contiguous(), Vh.contiguous()
+    comm.broadcast_(Uhat, s, Vh)
     Uk = Uhat[:, :k].T.contiguous().to(torch.float32)
     Ub = [kern.skinny(Q, Uk) for Q in Qmb]       # U = Q Uhat
     s = s[:k]

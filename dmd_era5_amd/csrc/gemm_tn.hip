@@ -154,8 +154,12 @@ __global__ __launch_bounds__(NTH, 2) void gemm_tn_partial_kernel(TnParams p) {
   // DMA: wave w, instruction i (0..3) fills columns 32w + 8i + (lane >> 3), the lane's
   // 16-byte slot (lane & 7) holds global k-chunk (lane & 7) ^ swz(col).
   // Register path: thread -> column (tid >> 3) + 32 i, k-chunk (tid & 7).
-  const float* aptr[4];
-  const float* bptr[4];
+  // addresses = wave-uniform tile base (SGPRs, advanced along K) + 32-bit per-lane element
+  // offset: the LDS-DMA then needs no per-instruction 64-bit VALU add
+  const int ra0 = row0 < p.nrow ? row0 : p.nrow - 1, cb0 = col0 < p.ncol ? col0 : p.ncol - 1;
+  const float* Abase = p.A + (int64_t)ra0 * p.lda;
+  const float* Bbase = p.B + (int64_t)cb0 * p.ldb;
+  unsigned aoff[4], boff[4];
   int sts[4];  // register path: float offset inside an operand stage
   int kq[4];   // 4 * (global k-chunk of this piece)
 #pragma unroll
@@ -165,8 +169,8 @@ __global__ __launch_bounds__(NTH, 2) void gemm_tn_partial_kernel(TnParams p) {
     int ca = (ABL & 4) ? lc : row0 + lc, cb = (ABL & 4) ? lc : col0 + lc;  // ABL 4: every unit streams panel 0
     ca = ca < p.nrow ? ca : p.nrow - 1;
     cb = cb < p.ncol ? cb : p.ncol - 1;
-    aptr[i] = p.A + (int64_t)ca * p.lda + 4 * q;
-    bptr[i] = p.B + (int64_t)cb * p.ldb + 4 * q;
+    aoff[i] = (unsigned)((int64_t)(ca - ra0) * p.lda + 4 * q);  // < 128 * lda: host checks it fits
+    boff[i] = (unsigned)((int64_t)(cb - cb0) * p.ldb + 4 * q);
     sts[i] = lc * BK + 4 * (DMA ? (lane & 7) : ((tid & 7) ^ swz(lc)));
     kq[i] = 4 * q;
   }
@@ -224,11 +228,11 @@ __global__ __launch_bounds__(NTH, 2) void gemm_tn_partial_kernel(TnParams p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       if (tail) {
-        ra[i] = load4_tail(aptr[i] + k0, k0 + kq[i], kend);
-        rb[i] = load4_tail(bptr[i] + k0, k0 + kq[i], kend);
+        ra[i] = load4_tail(Abase + k0 + aoff[i], k0 + kq[i], kend);
+        rb[i] = load4_tail(Bbase + k0 + boff[i], k0 + kq[i], kend);
       } else {
-        const float* pa = aptr[i] + k0;
-        const float* pb = bptr[i] + k0;
+        const float* pa = Abase + k0 + aoff[i];
+        const float* pb = Bbase + k0 + boff[i];
         ra[i] = f32x4{pa[0], pa[1], pa[2], pa[3]};
         rb[i] = f32x4{pb[0], pb[1], pb[2], pb[3]};
       }
@@ -247,8 +251,8 @@ __global__ __launch_bounds__(NTH, 2) void gemm_tn_partial_kernel(TnParams p) {
     float* bs = lds + (st * 2 + 1) * OPSZ + (32 * wave) * BK;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      __builtin_amdgcn_global_load_lds(DMDX_GLB_PTR(aptr[i] + k0), DMDX_LDS_PTR(as + 8 * i * BK), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds(DMDX_GLB_PTR(bptr[i] + k0), DMDX_LDS_PTR(bs + 8 * i * BK), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(DMDX_GLB_PTR(Abase + k0 + aoff[i]), DMDX_LDS_PTR(as + 8 * i * BK), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(DMDX_GLB_PTR(Bbase + k0 + boff[i]), DMDX_LDS_PTR(bs + 8 * i * BK), 16, 0, 0);
     }
   };
   auto stage = [&](int chunk, int st) {
@@ -296,9 +300,9 @@ __global__ __launch_bounds__(NTH, 2) void gemm_tn_partial_kernel(TnParams p) {
 #define DMDX_DMA_PAIR(i)                                                                          \
   do {                                                                                            \
     if (dma_next) {                                                                               \
-      __builtin_amdgcn_global_load_lds(DMDX_GLB_PTR(aptr[i] + knext),                             \
+      __builtin_amdgcn_global_load_lds(DMDX_GLB_PTR(Abase + knext + aoff[i]),                     \
                                        DMDX_LDS_PTR(dma_as + 8 * (i) * BK), 16, 0, 0);            \
-      __builtin_amdgcn_global_load_lds(DMDX_GLB_PTR(bptr[i] + knext),                             \
+      __builtin_amdgcn_global_load_lds(DMDX_GLB_PTR(Bbase + knext + boff[i]),                     \
                                        DMDX_LDS_PTR(dma_bs + 8 * (i) * BK), 16, 0, 0);            \
     }                                                                                             \
   } while (0)
@@ -543,6 +547,7 @@ int dmdx_syrk_f32(const float* X, int64_t m, int64_t n, int64_t ldx, double* G64
   DMDX_CHECK_ARG(m >= 1 && n >= 1 && n < (1 << 30), "syrk: bad shape m=%lld n=%lld", (long long)m,
                  (long long)n);
   DMDX_CHECK_ARG(ldx >= 1 && ldg >= n && (!G32 || ldg32 >= n), "syrk: bad leading dimension");
+  DMDX_CHECK_ARG(ldx < (1ll << 24), "syrk: ldx >= 2^24 not supported (use row blocks)");
   return run_tn(X, ldx, X, ldx, m, n, n, 1, G64, ldg, G32, ldg32, accumulate, workspace, workspace_bytes,
                 (hipStream_t)stream);
 }
@@ -560,6 +565,8 @@ int dmdx_gemm_tn_f32(const float* A, int64_t lda, const float* B, int64_t ldb, i
                  "gemm_tn: bad shape");
   DMDX_CHECK_ARG(lda >= 1 && ldb >= 1 && ldc >= na && (!C32 || ldc32 >= na),
                  "gemm_tn: bad leading dimension");
+  DMDX_CHECK_ARG(lda < (1ll << 24) && ldb < (1ll << 24),
+                 "gemm_tn: leading dimension >= 2^24 not supported (use row blocks)");
   // column-major C[a + b*ldc] == row-major D[b][a]: D rows <- B columns, D cols <- A columns
   return run_tn(B, ldb, A, lda, K, nb, na, 0, C64, ldc, C32, ldc32, accumulate, workspace, workspace_bytes,
                 (hipStream_t)stream);

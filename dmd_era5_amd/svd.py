@@ -132,8 +132,19 @@ def embed_view(Xt: torch.Tensor, d: int) -> torch.Tensor:
 # small dense pieces (fp64, torch)
 # ---------------------------------------------------------------------------
 def _orth(Y: torch.Tensor) -> torch.Tensor:
-    Q, _ = torch.linalg.qr(Y, mode="reduced")
-    return Q
+    """Orthonormal basis of the columns of a tall fp64 block.  CholeskyQR2 (two rounds of
+    Gram -> Cholesky -> triangular solve: three small GEMM-type calls, ~1 ms at 8760 x 210)
+    instead of Householder QR (rocSOLVER geqrf+orgqr: ~9 ms); falls back to Householder when
+    the block is too ill-conditioned for the Gram route."""
+    Q = Y
+    for _ in range(2):
+        G = Q.T @ Q
+        L, err = torch.linalg.cholesky_ex(G)
+        if int(err) != 0 or not torch.isfinite(L).all():
+            Qh, _ = torch.linalg.qr(Y, mode="reduced")
+            return Qh
+        Q = torch.linalg.solve_triangular(L, Q.T, upper=False).T
+    return Q.contiguous()
 
 
 def top_eigh(G: torch.Tensor, l: int, method: str = "auto", tol: float = 1e-11,
@@ -159,8 +170,8 @@ def top_eigh(G: torch.Tensor, l: int, method: str = "auto", tol: float = 1e-11,
         return lam, V.contiguous()
 
     b = min(n // 3, l + max(8, l // 4))
-    gen = torch.Generator(device="cpu").manual_seed(1234)
-    Q = torch.randn((n, b), dtype=torch.float64, generator=gen).to(G.device)
+    gen = torch.Generator(device=G.device).manual_seed(1234)  # (a host draw + upload costs 7 ms)
+    Q = torch.randn((n, b), dtype=torch.float64, generator=gen, device=G.device)
     Q = _orth(G @ Q)
     lam = V = None
     for it in range(max_outer):

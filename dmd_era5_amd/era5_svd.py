@@ -197,39 +197,117 @@ def combine_svd_results(U, s, V, coords, **kwargs) -> Dataset:
 # --------------------------------------------------------------------------------------
 # main: the device pipeline
 # --------------------------------------------------------------------------------------
+SLAB_BYTES = 256 << 20   # host staging slab of the streaming ingest
+
+
+def plan_selection(ds: Dataset, levels, delta_time):
+    """Index form of ``slice_era5_dataset(ds, levels=...)`` + ``resample_era5_dataset``
+    (ref era5_svd.py:385-388): which level indices and which time indices the SVD uses, and
+    the resulting time coordinate -- computed from the coordinates only, so that a
+    file-backed slice is never loaded whole.  Same validation / messages as slice_tools."""
+    have = list(ds.coords["level"].values)
+    levels = levels or have
+    missing = [lv for lv in levels if lv not in have]
+    if missing:
+        msg = f"Requested level is not available in the dataset.Available levels: {have}"
+        log_and_print(logger, msg, "error")
+        raise ValueError(msg)
+    level_idx = np.array([have.index(lv) for lv in levels])
+    times = ds.coords["time"].values
+    if len(times) < 2:
+        raise ValueError("Start datetime must be before end datetime.")
+    labels, take = nearest_resample_index(times, delta_time)
+    return level_idx, np.asarray(levels), take, labels
+
+
+def _upload_variable(da: DataArray, level_idx, take, device, kern, center, scale, stats):
+    """One variable (time, level, lat, lon) -> centred/scaled row blocks (time, rows) in HBM.
+
+    Streams time slabs: file/host -> pinned staging -> device slab -> strided device copy
+    into each row block.  Row order inside the variable: level slowest, longitude fastest."""
+    import torch
+
+    from . import svd as dsvd
+
+    order = [da.dims.index(x) for x in ("time", "level", "latitude", "longitude")]
+    if order != [0, 1, 2, 3]:
+        raise ValueError(f"variable {da.name}: expected dims (time, level, latitude, longitude), got {da.dims}")
+    n = len(take)
+    nlev_all, nlat, nlon = da.shape[1:]
+    m_v = len(level_idx) * nlat * nlon
+    ranges = dsvd.split_rows(m_v)
+    blocks = [torch.empty((n, b - a), dtype=torch.float32, device=device) for a, b in ranges]
+    lazy = da.lazy
+    host = None if lazy is not None else da.values
+    rows = max(1, SLAB_BYTES // max(1, nlev_all * nlat * nlon * 4))
+    contiguous = np.array_equal(take, np.arange(take[0], take[0] + n)) if n else True
+    all_levels = len(level_idx) == nlev_all and np.array_equal(level_idx, np.arange(nlev_all))
+    nbytes = 0
+    for j0 in range(0, n, rows):
+        j1 = min(n, j0 + rows)
+        if contiguous:
+            t0, t1 = int(take[j0]), int(take[j1 - 1]) + 1
+            slab = lazy.read_slab(t0, t1) if lazy is not None else host[t0:t1]
+        else:  # resampled: gather the selected snapshots
+            idx = take[j0:j1]
+            if lazy is not None:
+                lo, hi = int(idx.min()), int(idx.max()) + 1
+                slab = lazy.read_slab(lo, hi)[idx - lo]
+            else:
+                slab = host[idx]
+        if not all_levels:
+            slab = slab[:, level_idx]
+        slab = np.ascontiguousarray(slab.reshape(j1 - j0, m_v), dtype=np.float32)
+        nbytes += slab.nbytes
+        dev = torch.from_numpy(slab).to(device, non_blocking=False)
+        for (a, b), Xb in zip(ranges, blocks):
+            Xb[j0:j1].copy_(dev[:, a:b])
+        del dev
+    for Xb in blocks:
+        if center:
+            mu, sd = kern.row_center_scale_(Xb, bool(scale))
+            stats["mean"].append(mu)
+            if scale:
+                stats["std"].append(sd)
+    return blocks, m_v, nbytes
+
+
 def _device_pipeline(ds: Dataset, parsed_config: dict):
     """Slice -> (U, s, V, coords, X, X_mean, X_std) with X resident only in HBM.
 
     Row order = the reference's flatten order (variable-major, then level, latitude,
     longitude; ref slice_tools.py:311-336); embedding order k*m + s (ref :207-211)."""
+    import time as _time
+
     import torch
 
     from . import svd as dsvd
     from .kernels import default_kernels
 
     kern = default_kernels()
+    device = torch.device("cuda", torch.cuda.current_device())
     d = parsed_config["delay_embedding"]
     center, scale = parsed_config["mean_center"], parsed_config["scale"]
     names = list(ds.data_vars)
-    time = ds.coords["time"].values
-    one = space_labels(ds.coords["level"].values, ds.coords["latitude"].values, ds.coords["longitude"].values)
+    level_idx, levels, take, time = plan_selection(ds, parsed_config["levels"], parsed_config["delta_time"])
+    log_and_print(logger, f"Dataset slicing completed successfully using levels {list(levels)}")
+    log_and_print(logger, f"Resampled the dataset with time delta: {parsed_config['delta_time']}")
+    one = space_labels(levels, ds.coords["latitude"].values, ds.coords["longitude"].values)
     m_v = one.shape[0]
 
-    blocks, means, stds = [], [], []
+    t0 = _time.perf_counter()
+    blocks, stats, total = [], {"mean": [], "std": []}, 0
     for name in names:
-        da = ds[name]
-        order = [da.dims.index(x) for x in ("time", "level", "latitude", "longitude")]
-        A = np.transpose(da.values, order).reshape(len(time), m_v)       # (time, space) view
-        for a, b in dsvd.split_rows(m_v):
-            Xb = torch.from_numpy(np.ascontiguousarray(A[:, a:b], dtype=np.float32)).to("cuda")
-            if center:
-                mu, sd = kern.row_center_scale_(Xb, bool(scale))
-                means.append(mu)
-                if scale:
-                    stds.append(sd)
-            blocks.append(Xb)
-    m = m_v * len(names)
+        vb, mv, nbytes = _upload_variable(ds[name], level_idx, take, device, kern, center, scale, stats)
+        assert mv == m_v
+        blocks.extend(vb)
+        total += nbytes
+    torch.cuda.synchronize()
+    dt = _time.perf_counter() - t0
+    log_and_print(logger, f"Ingest: {total / 1e9:.3f} GB to HBM in {dt:.2f} s ({total / 1e9 / max(dt, 1e-9):.2f} GB/s, "
+                          f"{len(blocks)} row blocks, centre/scale on device)")
     k = parsed_config["n_components"]
+    t0 = _time.perf_counter()
     if parsed_config["svd_type"] == "standard":
         log_and_print(logger, "Performing standard SVD...")
         res = dsvd.svd_snapshots(blocks, k, delay=d)
@@ -238,7 +316,11 @@ def _device_pipeline(ds: Dataset, parsed_config: dict):
         log_and_print(logger, "Performing randomized SVD...")
         res = dsvd.svd_randomized(blocks, k, delay=d, **_engine_opts(parsed_config))
         log_and_print(logger, "Randomized SVD complete.")
-    out_dtype = ds[names[0]].values.dtype if ds[names[0]].values.dtype in (np.float32, np.float64) else np.float64
+    torch.cuda.synchronize()
+    dt = _time.perf_counter() - t0
+    log_and_print(logger, f"SVD stage: {dt:.3f} s ({total / 1e9 / max(dt, 1e-9):.1f} GB/s of X)")
+    src_dtype = ds[names[0]].dtype
+    out_dtype = src_dtype if src_dtype in (np.float32, np.float64) else np.float64
     U = res.Ut.cpu().numpy().T.astype(out_dtype, copy=False)
     s = res.s.cpu().numpy().astype(out_dtype, copy=False)
     V = res.Vh.cpu().numpy().astype(out_dtype, copy=False)
@@ -246,10 +328,10 @@ def _device_pipeline(ds: Dataset, parsed_config: dict):
     coords = delay_coords(np.tile(one, (len(names), 1)), np.repeat(names, m_v), time, d)
     X = X_mean = X_std = None
     if center and d > 1:  # the reference keeps the mean / std only in this case (ref :400-414)
-        mu = torch.cat(means).cpu().numpy().astype(out_dtype)
+        mu = torch.cat(stats["mean"]).cpu().numpy().astype(out_dtype)
         X_mean = DataArray(np.tile(mu, d), ("space",), {k_: coords[k_] for k_ in ("space", "original_variable")})
         if scale:
-            sd = torch.cat(stds).cpu().numpy().astype(out_dtype)
+            sd = torch.cat(stats["std"]).cpu().numpy().astype(out_dtype)
             X_std = DataArray(np.tile(sd, d), ("space",), {k_: coords[k_] for k_ in ("space", "original_variable")})
     if parsed_config["save_data_matrix"]:
         from .slice_tools import _apply_delay_embedding_np
@@ -294,8 +376,8 @@ def main(config: dict | None = None, write_to_netcdf: bool = False, use_dvc: boo
 
     try:
         ds = ds[parsed_config["variables"]]
-        ds = slice_era5_dataset(ds, levels=parsed_config["levels"])
-        ds = resample_era5_dataset(ds, parsed_config["delta_time"])
+        # slice_era5_dataset(levels=...) and resample_era5_dataset(...) happen inside, as index
+        # selections applied while the slice is streamed to the device
         U, s, V, coords, X, X_mean, X_std = _device_pipeline(ds, parsed_config)
         svd_results = combine_svd_results(U, s, V, coords, X=X, X_mean=X_mean, X_std=X_std)
         svd_results = add_config_attributes(svd_results, parsed_config)

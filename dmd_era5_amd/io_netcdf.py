@@ -6,12 +6,14 @@ the SVD result ``data/era5_svd/*.nc`` (ref: era5_svd.py:434, README.md:97-119).
 Backends, probed at run time:
   1. ``netCDF4`` (present wherever the reference itself is installed) -> NETCDF4/HDF5,
      the reference's format;
-  2. ``scipy.io.netcdf_file`` -> NetCDF-3 64-bit-offset.  Same variables, dimensions,
-     coordinates and attributes; ``xr.open_dataset`` reads it.  Limits of the classic
-     format apply (< 4 GiB per variable, no string variables: ``original_variable`` is
-     stored as an index plus the ``original_variables`` attribute).
-Neither xarray nor netCDF4 is installed in this image, so the tests here
-exercise backend 2.
+  2. :mod:`dmd_era5_amd.hdf5_lite` -- our ctypes binding of libhdf5 -> NETCDF4/HDF5 as well
+     (datasets + dimension scales + attributes, the layout netCDF-C reads), with lazy variables
+     and time-slab reads for the streaming ingest.  This is what runs in this image
+     (libhdf5 1.10.6 under /opt/conda/lib);
+  3. ``scipy.io.netcdf_file`` -> NetCDF-3 64-bit-offset, when no HDF5 library can be found.
+     Same variables / dimensions / attributes; limits of the classic format apply (< 4 GiB per
+     variable, no string variables: ``original_variable`` is stored as an index + flag_meanings).
+``DMDX_NETCDF_BACKEND`` = netcdf4 | hdf5 | scipy forces one (tests).
 """
 from __future__ import annotations
 
@@ -19,7 +21,8 @@ import os
 
 import numpy as np
 
-from .labeled import Coord, DataArray, Dataset
+from . import hdf5_lite
+from .labeled import Coord, DataArray, Dataset, LazyArray
 
 _EPOCH = np.datetime64("1970-01-01T00:00:00", "ns")
 TIME_UNITS = "hours since 1970-01-01 00:00:00"
@@ -78,14 +81,42 @@ def _safe_netcdf_file():
 
 
 # ----------------------------------------------------------------------------- write
-def to_netcdf(ds: Dataset, path: str) -> str:
-    """Write ``ds``; returns the backend used ("netCDF4" or "scipy-netcdf3")."""
-    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+def _backend() -> str:
+    forced = os.environ.get("DMDX_NETCDF_BACKEND", "").lower()
+    if forced in ("netcdf4", "hdf5", "scipy"):
+        return forced
     if _have_netcdf4():
+        return "netcdf4"
+    return "hdf5" if hdf5_lite.available() else "scipy"
+
+
+def to_netcdf(ds: Dataset, path: str) -> str:
+    """Write ``ds``; returns the backend used ("netCDF4", "hdf5-lite" or "scipy-netcdf3")."""
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    be = _backend()
+    if be == "netcdf4":
         _write_netcdf4(ds, path)
         return "netCDF4"
+    if be == "hdf5":
+        _write_hdf5(ds, path)
+        return "hdf5-lite"
     _write_scipy(ds, path)
     return "scipy-netcdf3"
+
+
+def _write_hdf5(ds: Dataset, path: str) -> None:
+    with hdf5_lite.Writer(path) as w:
+        for name, c in ds.coords.items():
+            vals, attrs = c.values, {}
+            if np.issubdtype(vals.dtype, np.datetime64):
+                vals = np.round(_encode_time(vals)).astype(np.int64)
+                attrs = {"units": TIME_UNITS, "calendar": "proleptic_gregorian"}
+            elif vals.ndim != 1:
+                continue  # (m, 3) space labels: stored as level / latitude / longitude
+            w.dataset(name, vals, c.dims, attrs)
+        for name, da in ds.data_vars.items():
+            w.dataset(name, np.asarray(da.values), da.dims, {k: v for k, v in da.attrs.items()})
+        w.attrs(None, dict(ds.attrs))
 
 
 def _prepared_vars(ds: Dataset):
@@ -154,11 +185,14 @@ def open_dataset(path: str) -> Dataset:
         magic = fh.read(4)
     if magic[:3] == b"CDF":
         return _read_scipy(path)
-    if _have_netcdf4():
+    be = _backend()
+    if be == "netcdf4":
         return _read_netcdf4(path)
+    if hdf5_lite.available():
+        return _read_hdf5(path)
     raise RuntimeError(
-        f"{path} is a NETCDF4/HDF5 file and the netCDF4 module is not installed in this "
-        "environment; install netCDF4 (it is a dependency of the reference) to read it.")
+        f"{path} is a NETCDF4/HDF5 file and neither the netCDF4 module nor libhdf5 was found "
+        "(set DMDX_HDF5_LIB to the directory holding libhdf5.so).")
 
 
 _ROW_COORDS = ("level", "latitude", "longitude", "original_variable", "delay")
@@ -167,7 +201,7 @@ _ROW_COORDS = ("level", "latitude", "longitude", "original_variable", "delay")
 def _assemble(raw: dict, dimsizes: dict, gattrs: dict) -> Dataset:
     coords, data = {}, {}
     for name, (dims, vals, attrs) in raw.items():
-        if "units" in attrs and " since " in str(attrs["units"]):
+        if "units" in attrs and " since " in str(attrs["units"]) and not isinstance(vals, LazyArray):
             vals = _decode_time(vals, attrs["units"].decode() if isinstance(attrs["units"], bytes) else attrs["units"])
         if name == "original_variable" and "flag_meanings" in attrs:
             fm = attrs["flag_meanings"]
@@ -180,6 +214,31 @@ def _assemble(raw: dict, dimsizes: dict, gattrs: dict) -> Dataset:
     ds = Dataset(coords=cds, attrs=gattrs)
     for k, (d, v, a) in data.items():
         ds[k] = DataArray(v, d, {c: cds[c] for c in cds if set(cds[c].dims) <= set(d)}, a)
+    return ds
+
+
+# variables above this size stay on disk until used (and can be streamed in time slabs)
+LAZY_BYTES = 64 << 20
+
+
+def _read_hdf5(path: str) -> Dataset:
+    r = hdf5_lite.Reader(path)
+    raw, sizes = {}, {}
+    for name, (shape, dt, dims) in r.variables.items():
+        if r.is_placeholder_dimension(name):
+            sizes[name] = shape[0]
+            continue
+        attrs = r.attrs(name)
+        nbytes = int(np.prod(shape)) * (dt.itemsize if hasattr(dt, "itemsize") else 8)
+        if nbytes > LAZY_BYTES and not isinstance(dt, str) and len(shape) >= 2:
+            vals = LazyArray(shape, dt, lambda n=name: r.read(n), lambda a, b, n=name: r.read_slab(n, a, b))
+        else:
+            vals = r.read(name)
+        raw[name] = (dims, vals, attrs)
+        for d, n in zip(dims, shape):
+            sizes[d] = n
+    ds = _assemble(raw, sizes, r.attrs(None))
+    ds._reader = r  # keeps the file open for the lazy variables
     return ds
 
 

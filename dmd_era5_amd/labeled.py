@@ -55,31 +55,59 @@ def _as_coords(coords) -> "OrderedDict[str, Coord]":
     return out
 
 
+class LazyArray:
+    """A file-backed array (like xarray's lazily opened variables): shape / dtype are known,
+    the data are read on first use, or in slabs along the first axis by the streaming ingest."""
+
+    def __init__(self, shape, dtype, read_all, read_slab):
+        self.shape, self.dtype, self.ndim = tuple(shape), np.dtype(dtype), len(shape)
+        self._read_all, self.read_slab = read_all, read_slab
+
+    def __array__(self, dtype=None, copy=None):
+        a = self._read_all()
+        return a.astype(dtype) if dtype is not None else a
+
+
 class DataArray:
     def __init__(self, values, dims, coords=None, attrs=None, name=None):
-        self.values = values if hasattr(values, "shape") else np.asarray(values)
+        self._values = values if hasattr(values, "shape") else np.asarray(values)
         self.dims = tuple(dims)
-        if len(self.dims) != self.values.ndim:
-            raise ValueError(f"dims {self.dims} do not match a {self.values.ndim}-D array")
+        if len(self.dims) != self._values.ndim:
+            raise ValueError(f"dims {self.dims} do not match a {self._values.ndim}-D array")
         self.coords = _as_coords(coords)
         self.attrs = dict(attrs or {})
         self.name = name
 
     @property
+    def values(self):
+        if isinstance(self._values, LazyArray):
+            self._values = np.asarray(self._values)
+        return self._values
+
+    @values.setter
+    def values(self, v):
+        self._values = v
+
+    @property
+    def lazy(self) -> "LazyArray | None":
+        """The file-backed array if the data have not been loaded yet, else None."""
+        return self._values if isinstance(self._values, LazyArray) else None
+
+    @property
     def shape(self):
-        return tuple(self.values.shape)
+        return tuple(self._values.shape)
 
     @property
     def ndim(self):
-        return self.values.ndim
+        return self._values.ndim
 
     @property
     def dtype(self):
-        return self.values.dtype
+        return self._values.dtype
 
     @property
     def sizes(self):
-        return dict(zip(self.dims, self.values.shape))
+        return dict(zip(self.dims, self._values.shape))
 
     def __repr__(self):
         return f"<DataArray {self.name or ''} {self.sizes} coords={list(self.coords)}>"

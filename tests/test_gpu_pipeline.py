@@ -102,3 +102,40 @@ def test_svd_on_era5_shapes_like_reference_test(svd_base_config, svd_type):
     assert col_cosines(U[:, :1], Ur[:, :1]).min() > 1 - 1e-6
     with pytest.raises(ValueError, match="SVD type foo is not supported."):
         svd_on_era5(da, dict(p, svd_type="foo"))
+
+
+def test_main_streams_a_lazy_hdf5_slice_with_resampling(svd_base_config, project_root, monkeypatch):
+    """File-backed variables (HDF5 backend), level subset in a different order, 6-hourly
+    nearest resampling, small staging slabs: the streaming ingest must build the same X."""
+    from dmd_era5_amd import era5_svd, io_netcdf
+    from dmd_era5_amd.era5_svd import main
+
+    monkeypatch.setenv("DMDX_NETCDF_BACKEND", "hdf5")
+    monkeypatch.setattr(io_netcdf, "LAZY_BYTES", 1000)
+    monkeypatch.setattr(era5_svd, "SLAB_BYTES", 7 * 3 * 36 * 72 * 4)      # 7 snapshots per slab
+    cfg = dict(svd_base_config, start_datetime="2019-01-01T00", end_datetime="2019-01-06T00",
+               delta_time="6h", variables="temperature,v_component_of_wind", levels="850,1000",
+               svd_type="standard", mean_center=True, scale=False, delay_embedding=2, n_components=5,
+               save_data_matrix=True)
+    wcfg = dict(cfg, delta_time="1h", levels="1000,925,850")
+    from dmd_era5_amd.config_parser import config_parser
+    from dmd_era5_amd.create_mock_data import add_download_attributes, create_mock_era5
+
+    p = config_parser(cfg, "era5-svd")
+    pw = config_parser(wcfg, "era5-svd")
+    full = add_download_attributes(
+        create_mock_era5(cfg["start_datetime"], cfg["end_datetime"], pw["variables"], pw["levels"], seed=4,
+                         dtype=np.float32), pw)
+    assert io_netcdf.to_netcdf(full, p["era5_slice_path"]) == "hdf5-lite"
+    res, _, _ = main(cfg, write_to_netcdf=True)
+    # oracle: levels [850, 1000] (requested order) of the 1000/925/850 file, every 6th hour
+    variables = {k: full[k].values[::6][:, [2, 0]] for k in p["variables"]}
+    X, X_mean, _ = orc.preprocess(variables, True, False, 2)
+    assert res["X"].shape == X.shape == (2 * 2 * 2 * 36 * 72, 20)
+    assert np.allclose(res["X"].values, X, rtol=0, atol=6e-3)
+    assert np.array_equal(res.coords["level"].values[:2 * 36 * 72], np.repeat([850.0, 1000.0], 36 * 72))
+    Uo, so, Vo = orc.svd_standard(X.astype(np.float64), 5)
+    assert np.allclose(res["s"].values, so, rtol=2e-5)
+    back = io_netcdf.open_dataset(p["save_path"])
+    assert np.allclose(back["s"].values, res["s"].values)
+    assert list(np.unique(back.coords["original_variable"].values)) == ["temperature", "v_component_of_wind"]

@@ -239,3 +239,56 @@ def test_main_reports_missing_slice_like_the_reference(svd_base_config, project_
 
     with pytest.raises(Exception, match="Error retrieving ERA5 slice"):
         main(svd_base_config)
+
+
+# ---- NETCDF4 through the ctypes HDF5 binding ------------------------------------------
+@pytest.mark.parametrize("backend", ["hdf5", "scipy"])
+def test_netcdf_backends_roundtrip_the_same_dataset(backend, tmp_path, monkeypatch):
+    from dmd_era5_amd import hdf5_lite
+
+    if backend == "hdf5" and not hdf5_lite.available():
+        pytest.skip("libhdf5 not found")
+    monkeypatch.setenv("DMDX_NETCDF_BACKEND", backend)
+    ds = create_mock_era5("2019-01-01", "2019-01-02", ["temperature", "u_component_of_wind"], [1000, 850],
+                          seed=8, dtype=np.float32)
+    ds.attrs.update(source_path="gs://x", variables=["temperature", "u_component_of_wind"], levels=[1000, 850],
+                    hours_delta_time=1.0, mean_center=True)
+    path = str(tmp_path / "slice.nc")
+    used = io_netcdf.to_netcdf(ds, path)
+    assert used == ("hdf5-lite" if backend == "hdf5" else "scipy-netcdf3")
+    with open(path, "rb") as fh:
+        assert fh.read(4) == (b"\x89HDF" if backend == "hdf5" else b"CDF\x02")
+    back = io_netcdf.open_dataset(path)
+    assert list(back.data_vars) == ["temperature", "u_component_of_wind"]
+    assert back["temperature"].dims == ("time", "level", "latitude", "longitude")
+    assert np.array_equal(back["temperature"].values, ds["temperature"].values)
+    assert np.array_equal(back.coords["time"].values, ds.coords["time"].values)
+    assert list(back.coords["level"].values) == [1000, 850]
+    from dmd_era5_amd.era5_svd import _as_int_list, _as_str_list
+
+    assert _as_str_list(back.attrs["variables"]) == ["temperature", "u_component_of_wind"]
+    assert _as_int_list(back.attrs["levels"]) == [1000, 850]
+    assert back.attrs["source_path"] == "gs://x" and back.attrs["mean_center"] == 1
+
+
+def test_hdf5_lazy_variables_and_time_slabs(tmp_path, monkeypatch):
+    from dmd_era5_amd import hdf5_lite
+
+    if not hdf5_lite.available():
+        pytest.skip("libhdf5 not found")
+    monkeypatch.setenv("DMDX_NETCDF_BACKEND", "hdf5")
+    monkeypatch.setattr(io_netcdf, "LAZY_BYTES", 1000)
+    ds = create_mock_era5("2019-01-01", "2019-01-03", ["temperature"], [1000, 850, 500], seed=3, dtype=np.float32)
+    path = str(tmp_path / "lazy.nc")
+    io_netcdf.to_netcdf(ds, path)
+    back = io_netcdf.open_dataset(path)
+    lazy = back["temperature"].lazy
+    assert lazy is not None and lazy.shape == (49, 3, 36, 72) and lazy.dtype == np.float32
+    assert np.array_equal(lazy.read_slab(10, 17), ds["temperature"].values[10:17])
+    assert back["temperature"].lazy is not None          # slab reads do not load the variable
+    assert np.array_equal(back["temperature"].values, ds["temperature"].values)
+    assert back["temperature"].lazy is None              # .values loaded it
+    # dimension scales make the file a NETCDF4 file: every variable knows its dimension names
+    with hdf5_lite.Reader(path) as r:
+        assert r.variables["temperature"][2] == ("time", "level", "latitude", "longitude")
+        assert r.attrs("time")["units"].startswith("hours since")

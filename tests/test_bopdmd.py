@@ -1,0 +1,112 @@
+"""Known-answer tests of the optimized-DMD fit (BASELINE config 5).  Parity with pydmd is
+unpinned (pydmd is not available anywhere), so the algorithm is pinned on
+planted signals: sums of damped complex exponentials with chosen eigenvalues."""
+import numpy as np
+import pytest
+import torch
+
+from dmd_era5_amd import bopdmd as bop
+
+ALPHA = np.array([-0.1 + 2.0j, -0.1 - 2.0j, -0.5 + 5.0j, -0.5 - 5.0j, -0.02 + 0.7j, -0.02 - 0.7j])
+
+
+def _signal(t, n_s=12, noise=0.0, seed=0, alpha=ALPHA):
+    rs = np.random.RandomState(seed)
+    modes = rs.standard_normal((len(alpha), n_s)) + 1j * rs.standard_normal((len(alpha), n_s))
+    H = np.exp(np.outer(t, alpha)) @ modes
+    if noise:
+        H = H + noise * (rs.standard_normal(H.shape) + 1j * rs.standard_normal(H.shape))
+    return torch.from_numpy(H), modes
+
+
+def _err(found, truth):
+    f = found.numpy()
+    return max(np.min(np.abs(f - a)) for a in truth)
+
+
+def test_recovers_planted_eigenvalues_noise_free():
+    t = torch.linspace(0, 6, 300, dtype=torch.float64)
+    H, modes = _signal(t.numpy())
+    res = bop.optdmd(H, t, 6)                      # default tol 1e-6 on the relative residual
+    assert res.converged and res.rel_error < 1e-6 and _err(res.eigs, ALPHA) < 1e-5
+    res = bop.optdmd(H, t, 6, tol=1e-11, maxiter=60)
+    assert res.rel_error < 1e-9
+    assert _err(res.eigs, ALPHA) < 1e-8
+    assert torch.allclose(res.reconstruct(t), H, atol=1e-5 * float(H.abs().max()))
+    assert torch.allclose(torch.linalg.norm(res.modes, dim=0), torch.ones(6, dtype=torch.float64))
+
+
+def test_uneven_sampling_and_noise():
+    rs = np.random.RandomState(1)
+    t = np.sort(rs.uniform(0, 6, 400))
+    H, _ = _signal(t, noise=1e-3, seed=2)
+    res = bop.optdmd(H, torch.from_numpy(t), 6, tol=1e-9)
+    assert _err(res.eigs, ALPHA) < 5e-3
+    assert res.rel_error < 5e-3
+    # the trapezoidal initial guess alone is much worse than the fit (it is only an initial guess)
+    a0 = bop.trapezoidal_dmd_eigs(H, torch.from_numpy(t).to(H.dtype), 6)
+    assert _err(a0, ALPHA) > _err(res.eigs, ALPHA)
+
+
+def test_monotone_error_and_bad_start():
+    t = torch.linspace(0, 5, 250, dtype=torch.float64)
+    H, _ = _signal(t.numpy(), noise=1e-4, seed=3)
+    start = torch.from_numpy(ALPHA * (1 + 0.15 * np.random.RandomState(4).standard_normal(6)))
+    res = bop.optdmd(H, t, 6, alpha0=start, maxiter=60)
+    errs = res.info["errors"]
+    assert all(b <= a + 1e-15 for a, b in zip(errs, errs[1:])), "LM must never accept a worse iterate"
+    assert _err(res.eigs, ALPHA) < 1e-3
+
+
+def test_bagging_reports_spread_and_stays_on_target():
+    t = torch.linspace(0, 6, 400, dtype=torch.float64)
+    H, _ = _signal(t.numpy(), noise=2e-3, seed=5)
+    res = bop.bopdmd(H, t, 6, num_trials=8, trial_size=0.5, seed=0)
+    assert res.eigs_std is not None and res.eigs_std.shape == (6,)
+    assert float(res.eigs_std.max()) < 5e-2 and float(res.eigs_std.max()) > 0
+    assert _err(res.eigs, ALPHA) < 1e-2
+
+
+def test_on_reduced_coordinates_of_an_svd():
+    """cfg-5 shape in miniature: H = V_r S from a snapshot SVD whose time dynamics are planted."""
+    rs = np.random.RandomState(7)
+    t = np.linspace(0, 8, 256)
+    alpha = np.array([-0.05 + 1.5j, -0.05 - 1.5j, -0.2 + 3.1j, -0.2 - 3.1j])
+    dyn = np.exp(np.outer(t, alpha))                                      # (n, 4)
+    spatial = rs.standard_normal((4, 500)) + 1j * rs.standard_normal((4, 500))
+    X = np.real(dyn @ spatial).T                                          # (space, time), real, rank 4
+    U, s, Vh = np.linalg.svd(X, full_matrices=False)
+    H = bop.reduced_coordinates(torch.from_numpy(s[:4]), torch.from_numpy(Vh[:4]))
+    assert H.shape == (256, 4)
+    res = bop.optdmd(H, torch.from_numpy(t), 4)
+    assert _err(res.eigs, alpha) < 1e-6
+    # full-space modes = U_r @ reduced modes reproduce the data
+    rec = (U[:, :4] @ res.reconstruct(torch.from_numpy(t)).T.numpy())
+    assert np.allclose(rec.real, X, atol=1e-6 * np.abs(X).max())
+
+
+def test_float32_path():
+    t = torch.linspace(0, 4, 200, dtype=torch.float32)
+    H, _ = _signal(t.numpy().astype(np.float64), n_s=8)
+    res = bop.optdmd(H.to(torch.complex64), t, 6, tol=1e-4)
+    assert res.eigs.dtype == torch.complex64
+    assert _err(res.eigs.to(torch.complex128), ALPHA) < 5e-3
+
+
+@pytest.mark.gpu
+def test_cfg5_shape_on_device():
+    """BASELINE config 5 in shape: n = 8760 snapshots, rank-r reduced coordinates, on the GPU.
+    Planted eigenvalues (slowly damped oscillations, hourly sampling over a year in units of days)."""
+    rs = np.random.RandomState(0)
+    r = 40
+    t = np.arange(8760) / 24.0
+    freq = np.sort(rs.uniform(0.02, 3.0, r // 2))
+    alpha = np.concatenate([-rs.uniform(1e-4, 3e-3, r // 2) + 1j * 2 * np.pi * freq])
+    alpha = np.concatenate([alpha, alpha.conj()])
+    H, _ = _signal(t, n_s=r, noise=1e-6, seed=1, alpha=alpha)
+    Hd, td = H.cuda(), torch.from_numpy(t).cuda()
+    start = torch.from_numpy(alpha * (1 + 1e-3 * rs.standard_normal(r))).cuda()
+    res = bop.optdmd(Hd, td, r, alpha0=start, tol=1e-8, maxiter=40)
+    assert res.eigs.is_cuda
+    assert _err(res.eigs.cpu(), alpha) < 1e-5
+    assert res.rel_error < 1e-4

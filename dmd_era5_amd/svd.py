@@ -377,16 +377,29 @@ def svd_snapshots(Xt, n_components: int, delay: int = 1, oversample: int | None 
 def _cholqr(Yb, comm: Comm, kern, passes: int = 1):
     """Orthonormalise the columns of the tall matrix Y given as row blocks
     (each (l, M_b)): G = Y^T Y (l x l, summed over blocks and ranks), G = R^T R,
-    Y <- Y R^-1."""
+    Y <- Y R^-1.
+
+    CholeskyQR needs cond(Y)^2 below the accuracy of the fp32-product Gram (~1e8).  Oversampled
+    range-finder blocks reach past the numerical rank of X, so when the factorisation fails (or
+    its pivots collapse) the pass is redone as *shifted* CholeskyQR (Fukaya et al. 2020):
+    factor G + s I with s ~ 1e-6 trace(G), which caps the conditioning of Y R^-1 at ~1e3, and one
+    extra plain pass is appended to restore orthonormality.  The span of Y is unchanged."""
     l = Yb[0].shape[0]
     eye = torch.eye(l, dtype=torch.float64, device=Yb[0].device)
-    for _ in range(passes):
+    todo, done = passes, 0
+    while todo > 0 and done < passes + 3:
+        done += 1
+        todo -= 1
         G = _gram_blocks(Yb, kern, comm)
         G = 0.5 * (G + G.T)
         L, err = torch.linalg.cholesky_ex(G)
-        if int(err) != 0:  # numerically rank deficient: shift (keeps the span)
-            shift = 1e-12 * torch.diagonal(G).sum()
+        diag = torch.diagonal(L)
+        bad = int(err) != 0 or not bool(torch.isfinite(diag).all()) or \
+            float(diag.min()) < 1e-4 * float(diag.max())
+        if bad:
+            shift = 1e-6 * torch.diagonal(G).sum()
             L = torch.linalg.cholesky(G + shift * eye)
+            todo += 1
         Rinv = torch.linalg.solve_triangular(L.T, eye, upper=True)  # R = L^T
         Rt = comm.broadcast_(Rinv.T.contiguous().to(torch.float32))
         Yb = [kern.skinny(Y, Rt) for Y in Yb]

@@ -116,7 +116,7 @@ __device__ inline f32x4 load4_tail(const float* p, int64_t k, int64_t kend) {
 //              bases and leading dimensions); the K-tail chunk goes through registers.
 // DMA = false: everything register-staged with scalar loads (any alignment).
 // ABL: timing-only ablations for diagnosis (results are wrong when ABL != 0):
-//   1 no global->LDS staging, 2 no barrier, 4 all units stream the same panel, 8 no fp64 fold.  Selected by DMDX_TN_ABLATE.
+//   1 no global->LDS staging, 2 no barrier, 8 no fp64 fold (none of them changes an address).  Selected by DMDX_TN_ABLATE.
 template <bool DMA, int ABL = 0>
 __global__ __launch_bounds__(NTH, 2) void gemm_tn_partial_kernel(TnParams p) {
   __shared__ __attribute__((aligned(16))) float lds[2 * 2 * BT * BK];
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(NTH, 2) void gemm_tn_partial_kernel(TnParams p) {
   for (int i = 0; i < 4; ++i) {
     const int lc = DMA ? 32 * wave + 8 * i + (lane >> 3) : (tid >> 3) + 32 * i;  // local column
     const int q = DMA ? ((lane & 7) ^ swz(lc)) : (tid & 7);                       // global k-chunk
-    int ca = (ABL & 4) ? lc : row0 + lc, cb = (ABL & 4) ? lc : col0 + lc;  // ABL 4: every unit streams panel 0
+    int ca = row0 + lc, cb = col0 + lc;
     ca = ca < p.nrow ? ca : p.nrow - 1;
     cb = cb < p.ncol ? cb : p.ncol - 1;
     aoff[i] = (unsigned)((int64_t)(ca - ra0) * p.lda + 4 * q);  // < 128 * lda: host checks it fits
@@ -516,8 +516,6 @@ int run_tn(const float* A, int64_t lda, const float* B, int64_t ldb, int64_t K, 
     hipLaunchKernelGGL((gemm_tn_partial_kernel<true, 2>), grid, dim3(NTH), 0, stream, p);
   else if (aligned && abl == 8)
     hipLaunchKernelGGL((gemm_tn_partial_kernel<true, 8>), grid, dim3(NTH), 0, stream, p);
-  else if (aligned && abl == 4)
-    hipLaunchKernelGGL((gemm_tn_partial_kernel<true, 4>), grid, dim3(NTH), 0, stream, p);
   else if (aligned && abl == 11)
     hipLaunchKernelGGL((gemm_tn_partial_kernel<true, 11>), grid, dim3(NTH), 0, stream, p);
   else if (aligned)  // LDS-DMA staging needs 16-byte aligned column starts

@@ -35,7 +35,6 @@ constexpr int BK = 32;             // K rows per stage
 constexpr int FOLD = 128;          // chunks per fp32 chain (128 * 32 = 4096 rows) before the fp64 fold
 constexpr int NTH = 256;
 // fp32 chain length = 32 chunks * 32 rows = 1024 rows (hard-wired in the fold schedule)
-constexpr int TILE_ELEMS = BT * BT;
 
 struct TnParams {
   const float* A;   // MFMA "A" operand source: D rows
@@ -117,11 +116,17 @@ __device__ inline f32x4 load4_tail(const float* p, int64_t k, int64_t kend) {
 // DMA = false: everything register-staged with scalar loads (any alignment).
 // ABL: timing-only ablations for diagnosis (results are wrong when ABL != 0):
 //   1 no global->LDS staging, 2 no barrier, 8 no fp64 fold (none of them changes an address).  Selected by DMDX_TN_ABLATE.
-template <bool DMA, int ABL = 0>
+// SK ("skinny rows"): 64 x 128 output tile, the four waves side by side (each 64 rows x 32
+//   columns = 2 x 1 MFMA blocks) -- for D with few rows (Z = X^T Y with l <= 64 columns of Y):
+//   half the MFMA work of a 128-row tile that would be half padding.
+template <bool DMA, int ABL = 0, bool SK = false>
 __global__ __launch_bounds__(NTH, 2) void gemm_tn_partial_kernel(TnParams p) {
-  __shared__ __attribute__((aligned(16))) float lds[2 * 2 * BT * BK];
-  // stage st, operand o (0 = A, 1 = B): lds + (st * 2 + o) * BT * BK
-  constexpr int OPSZ = BT * BK;  // floats per operand stage (16 KB)
+  constexpr int TM = SK ? 64 : BT;   // tile rows    (columns of OpA)
+  constexpr int NI = SK ? 1 : 2;     // 32-column MFMA blocks per wave
+  constexpr int NPA = SK ? 2 : 4;    // 1 KiB pieces of the A panel per wave (or 16 B pieces per thread)
+  constexpr int OPA = TM * BK, OPB = BT * BK, STG = OPA + OPB;  // floats per stage
+  __shared__ __attribute__((aligned(16))) float lds[2 * STG];
+  // stage st: A panel at lds + st * STG, B panel at lds + st * STG + OPA
 
   // ---- unit decode (XCD-aware) ----
   const int total = gridDim.x;
@@ -132,7 +137,7 @@ __global__ __launch_bounds__(NTH, 2) void gemm_tn_partial_kernel(TnParams p) {
   const int tile = pos - split * p.ntiles;
   int ta, tb;
   decode_tile(p, tile, ta, tb);
-  const int row0 = ta * BT;  // D rows  <- columns of A
+  const int row0 = ta * TM;  // D rows  <- columns of A
   const int col0 = tb * BT;  // D cols  <- columns of B
 
   const int c_begin = split * p.chunks_per_split;
@@ -146,7 +151,7 @@ __global__ __launch_bounds__(NTH, 2) void gemm_tn_partial_kernel(TnParams p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 1, wc = wave & 1;
+  const int wr = SK ? 0 : wave >> 1, wc = SK ? wave : wave & 1;
   const int l31 = lane & 31, lh = lane >> 5;
 
   // ---- staging assignment.  Columns past the matrix edge are clamped onto the last
@@ -159,27 +164,35 @@ __global__ __launch_bounds__(NTH, 2) void gemm_tn_partial_kernel(TnParams p) {
   const int ra0 = row0 < p.nrow ? row0 : p.nrow - 1, cb0 = col0 < p.ncol ? col0 : p.ncol - 1;
   const float* Abase = p.A + (int64_t)ra0 * p.lda;
   const float* Bbase = p.B + (int64_t)cb0 * p.ldb;
-  unsigned aoff[4], boff[4];
-  int sts[4];  // register path: float offset inside an operand stage
-  int kq[4];   // 4 * (global k-chunk of this piece)
+  unsigned aoff[NPA], boff[4];
+  int stsa[NPA], stsb[4];  // register path: float offset inside an operand stage
+  int kqa[NPA], kqb[4];    // 4 * (global k-chunk of this piece)
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int lc = DMA ? 32 * wave + 8 * i + (lane >> 3) : (tid >> 3) + 32 * i;  // local column
     const int q = DMA ? ((lane & 7) ^ swz(lc)) : (tid & 7);                       // global k-chunk
-    int ca = row0 + lc, cb = col0 + lc;
-    ca = ca < p.nrow ? ca : p.nrow - 1;
+    int cb = col0 + lc;
     cb = cb < p.ncol ? cb : p.ncol - 1;
-    aoff[i] = (unsigned)((int64_t)(ca - ra0) * p.lda + 4 * q);  // < 128 * lda: host checks it fits
-    boff[i] = (unsigned)((int64_t)(cb - cb0) * p.ldb + 4 * q);
-    sts[i] = lc * BK + 4 * (DMA ? (lane & 7) : ((tid & 7) ^ swz(lc)));
-    kq[i] = 4 * q;
+    boff[i] = (unsigned)((int64_t)(cb - cb0) * p.ldb + 4 * q);  // < 128 * ld: host checks it fits
+    stsb[i] = lc * BK + 4 * (DMA ? (lane & 7) : ((tid & 7) ^ swz(lc)));
+    kqb[i] = 4 * q;
+  }
+#pragma unroll
+  for (int i = 0; i < NPA; ++i) {
+    const int lc = DMA ? (TM / 4) * wave + 8 * i + (lane >> 3) : (tid >> 3) + 32 * i;
+    const int q = DMA ? ((lane & 7) ^ swz(lc)) : (tid & 7);
+    int ca = row0 + lc;
+    ca = ca < p.nrow ? ca : p.nrow - 1;
+    aoff[i] = (unsigned)((int64_t)(ca - ra0) * p.lda + 4 * q);
+    stsa[i] = lc * BK + 4 * (DMA ? (lane & 7) : ((tid & 7) ^ swz(lc)));
+    kqa[i] = 4 * q;
   }
 
-  f32x16 acc[2][2];
+  f32x16 acc[2][NI];
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
+    for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
@@ -188,8 +201,8 @@ __global__ __launch_bounds__(NTH, 2) void gemm_tn_partial_kernel(TnParams p) {
   // FOLD*32 rows), the four blocks staggered by FOLD/4 chunks so that at most one
   // block's 16 old values are in flight (prefetched one chunk ahead of the fold).
   // The partial tile is streamed (non-temporal): it is touched once per FOLD chunks.
-  double* Pt = p.P + ((size_t)split * p.ntiles + tile) * TILE_ELEMS;
-  const int lane_off = (64 * wr + 4 * lh) * BT + 64 * wc + l31;
+  double* Pt = p.P + ((size_t)split * p.ntiles + tile) * (TM * BT);
+  const int lane_off = (64 * wr + 4 * lh) * BT + (SK ? 32 : 64) * wc + l31;
   double oldv[16];
 #define DMDX_BLOCK_OFF(mi, ni, r) ((32 * (mi) + ((r) & 3) + 8 * ((r) >> 2)) * BT + 32 * (ni))
 #define DMDX_PREFETCH(mi, ni)                                                     \
@@ -215,43 +228,43 @@ __global__ __launch_bounds__(NTH, 2) void gemm_tn_partial_kernel(TnParams p) {
 
   if (nchunks <= 0) {  // empty split: the partial tile must still be defined
     DMDX_COMMIT(0, 0, false);
-    DMDX_COMMIT(0, 1, false);
     DMDX_COMMIT(1, 0, false);
-    DMDX_COMMIT(1, 1, false);
+    if constexpr (NI == 2) {
+      DMDX_COMMIT(0, 1, false);
+      DMDX_COMMIT(1, 1, false);
+    }
     return;
   }
 
   // ---- global -> LDS for one chunk into stage st
   auto stage_regs = [&](int chunk, int st, bool tail) {  // register path (tail / unaligned)
     const int64_t k0 = (int64_t)chunk * BK;
-    f32x4 ra[4], rb[4];
+    f32x4 ra[NPA], rb[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      if (tail) {
-        ra[i] = load4_tail(Abase + k0 + aoff[i], k0 + kq[i], kend);
-        rb[i] = load4_tail(Bbase + k0 + boff[i], k0 + kq[i], kend);
-      } else {
-        const float* pa = Abase + k0 + aoff[i];
-        const float* pb = Bbase + k0 + boff[i];
-        ra[i] = f32x4{pa[0], pa[1], pa[2], pa[3]};
-        rb[i] = f32x4{pb[0], pb[1], pb[2], pb[3]};
-      }
+      const float* pb = Bbase + k0 + boff[i];
+      rb[i] = tail ? load4_tail(pb, k0 + kqb[i], kend) : f32x4{pb[0], pb[1], pb[2], pb[3]};
     }
-    float* as = lds + (st * 2 + 0) * OPSZ;
-    float* bs = lds + (st * 2 + 1) * OPSZ;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      *reinterpret_cast<f32x4*>(as + sts[i]) = ra[i];
-      *reinterpret_cast<f32x4*>(bs + sts[i]) = rb[i];
+    for (int i = 0; i < NPA; ++i) {
+      const float* pa = Abase + k0 + aoff[i];
+      ra[i] = tail ? load4_tail(pa, k0 + kqa[i], kend) : f32x4{pa[0], pa[1], pa[2], pa[3]};
     }
+    float* as = lds + st * STG;
+    float* bs = lds + st * STG + OPA;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(bs + stsb[i]) = rb[i];
+#pragma unroll
+    for (int i = 0; i < NPA; ++i) *reinterpret_cast<f32x4*>(as + stsa[i]) = ra[i];
   };
   auto stage_dma = [&](int chunk, int st) {
     const int64_t k0 = (int64_t)chunk * BK;
-    float* as = lds + (st * 2 + 0) * OPSZ + (32 * wave) * BK;
-    float* bs = lds + (st * 2 + 1) * OPSZ + (32 * wave) * BK;
+    float* as = lds + st * STG + ((TM / 4) * wave) * BK;
+    float* bs = lds + st * STG + OPA + (32 * wave) * BK;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      __builtin_amdgcn_global_load_lds(DMDX_GLB_PTR(Abase + k0 + aoff[i]), DMDX_LDS_PTR(as + 8 * i * BK), 16, 0, 0);
+      if (i < NPA)
+        __builtin_amdgcn_global_load_lds(DMDX_GLB_PTR(Abase + k0 + aoff[i < NPA ? i : 0]), DMDX_LDS_PTR(as + 8 * i * BK), 16, 0, 0);
       __builtin_amdgcn_global_load_lds(DMDX_GLB_PTR(Bbase + k0 + boff[i]), DMDX_LDS_PTR(bs + 8 * i * BK), 16, 0, 0);
     }
   };
@@ -267,28 +280,19 @@ __global__ __launch_bounds__(NTH, 2) void gemm_tn_partial_kernel(TnParams p) {
   // ---- MFMA operand fragments, two register sets: the set for k-step t+1 is read from
   // LDS while the 16 MFMAs of k-step t run.  Lane (r = lane&31, h = lane>>5) reads, for
   // k-step t, the 16-byte k-chunk (2t + h) of its column, stored at slot (2t+h) ^ swz.
-  f32x4 fa0[2], fb0[2], fa1[2], fb1[2];
+  f32x4 fa0[2], fb0[NI], fa1[2], fb1[NI];
   int foff[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) foff[t] = l31 * BK + 4 * ((2 * t + lh) ^ swz(l31));
-  const int frag_a = 64 * wr * BK, frag_b = 64 * wc * BK;
+  const int frag_a = 64 * wr * BK, frag_b = (SK ? 32 : 64) * wc * BK;
 #define DMDX_READ_FRAGS(FA, FB, st, t)                                               \
   do {                                                                               \
-    const float* as_ = lds + ((st) * 2 + 0) * OPSZ + frag_a + foff[t];               \
-    const float* bs_ = lds + ((st) * 2 + 1) * OPSZ + frag_b + foff[t];               \
+    const float* as_ = lds + (st) * STG + frag_a + foff[t];                          \
+    const float* bs_ = lds + (st) * STG + OPA + frag_b + foff[t];                    \
     FA[0] = *reinterpret_cast<const f32x4*>(as_);                                    \
     FA[1] = *reinterpret_cast<const f32x4*>(as_ + 32 * BK);                          \
     FB[0] = *reinterpret_cast<const f32x4*>(bs_);                                    \
-    FB[1] = *reinterpret_cast<const f32x4*>(bs_ + 32 * BK);                          \
-  } while (0)
-#define DMDX_MFMA16(FA, FB)                                                                   \
-  do {                                                                                        \
-    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                           \
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[0][j], FB[0][j], acc[0][0], 0, 0, 0); \
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[0][j], FB[1][j], acc[0][1], 0, 0, 0); \
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[1][j], FB[0][j], acc[1][0], 0, 0, 0); \
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[1][j], FB[1][j], acc[1][1], 0, 0, 0); \
-    }                                                                                         \
+    if constexpr (NI == 2) FB[NI - 1] = *reinterpret_cast<const f32x4*>(bs_ + 32 * BK); \
   } while (0)
 
   stage(c_begin, 0);
@@ -300,27 +304,27 @@ __global__ __launch_bounds__(NTH, 2) void gemm_tn_partial_kernel(TnParams p) {
 #define DMDX_DMA_PAIR(i)                                                                          \
   do {                                                                                            \
     if (dma_next) {                                                                               \
-      __builtin_amdgcn_global_load_lds(DMDX_GLB_PTR(Abase + knext + aoff[i]),                     \
-                                       DMDX_LDS_PTR(dma_as + 8 * (i) * BK), 16, 0, 0);            \
+      if constexpr ((i) < NPA)                                                                    \
+        __builtin_amdgcn_global_load_lds(DMDX_GLB_PTR(Abase + knext + aoff[(i) < NPA ? (i) : 0]), \
+                                         DMDX_LDS_PTR(dma_as + 8 * (i) * BK), 16, 0, 0);          \
       __builtin_amdgcn_global_load_lds(DMDX_GLB_PTR(Bbase + knext + boff[i]),                     \
                                        DMDX_LDS_PTR(dma_bs + 8 * (i) * BK), 16, 0, 0);            \
     }                                                                                             \
   } while (0)
 #define DMDX_MFMA4(FA, FB, j)                                                                   \
   do {                                                                                          \
-    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[0][j], FB[0][j], acc[0][0], 0, 0, 0);   \
-    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[0][j], FB[1][j], acc[0][1], 0, 0, 0);   \
-    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[1][j], FB[0][j], acc[1][0], 0, 0, 0);   \
-    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[1][j], FB[1][j], acc[1][1], 0, 0, 0);   \
+    _Pragma("unroll") for (int mi_ = 0; mi_ < 2; ++mi_)                                         \
+        _Pragma("unroll") for (int ni_ = 0; ni_ < NI; ++ni_) acc[mi_][ni_] =                    \
+            __builtin_amdgcn_mfma_f32_32x32x2f32(FA[mi_][j], FB[ni_][j], acc[mi_][ni_], 0, 0, 0); \
   } while (0)
-  // k-step: [4 ds_read of the next fragments] 16 MFMA
+  // k-step: [2 + NI ds_read of the next fragments] 8 * NI MFMA
 #define DMDX_KSTEP(FA, FB, i)                                      \
   do {                                                             \
     DMDX_MFMA4(FA, FB, 0);                                         \
     DMDX_MFMA4(FA, FB, 1);                                         \
     DMDX_MFMA4(FA, FB, 2);                                         \
     DMDX_MFMA4(FA, FB, 3);                                         \
-    __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);            \
+    __builtin_amdgcn_sched_group_barrier(0x008, 8 * NI, 0);        \
   } while (0)
 
   int cur = 0;
@@ -328,15 +332,15 @@ __global__ __launch_bounds__(NTH, 2) void gemm_tn_partial_kernel(TnParams p) {
     const bool has_next = (c + 1 < nchunks) && !(ABL & 1);
     const bool dma_next = DMA && has_next && (c_begin + c + 1 != tail_chunk);
     const int64_t knext = (int64_t)(c_begin + c + 1) * BK;
-    float* dma_as = lds + ((cur ^ 1) * 2 + 0) * OPSZ + (32 * wave) * BK;
-    float* dma_bs = lds + ((cur ^ 1) * 2 + 1) * OPSZ + (32 * wave) * BK;
+    float* dma_as = lds + (cur ^ 1) * STG + ((TM / 4) * wave) * BK;
+    float* dma_bs = lds + (cur ^ 1) * STG + OPA + (32 * wave) * BK;
     const int phase = c & (FOLD / 4 - 1), fq = (c / (FOLD / 4)) & 3;
     if (!(ABL & 8) && phase == FOLD / 4 - 2 && c >= FOLD) {  // old partial values of block fq, used one chunk later
       switch (fq) {
         case 0: DMDX_PREFETCH(0, 0); break;
-        case 1: DMDX_PREFETCH(0, 1); break;
+        case 1: if constexpr (NI == 2) { DMDX_PREFETCH(0, NI - 1); } break;
         case 2: DMDX_PREFETCH(1, 0); break;
-        default: DMDX_PREFETCH(1, 1); break;
+        default: if constexpr (NI == 2) { DMDX_PREFETCH(1, NI - 1); } break;
       }
     }
 
@@ -345,13 +349,13 @@ __global__ __launch_bounds__(NTH, 2) void gemm_tn_partial_kernel(TnParams p) {
     DMDX_DMA_PAIR(2);
     DMDX_DMA_PAIR(3);
     DMDX_READ_FRAGS(fa1, fb1, cur, 1);
-    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);   // 4 ds_read
+    __builtin_amdgcn_sched_group_barrier(0x100, 2 + NI, 0);   // ds_reads of the next fragments
     DMDX_KSTEP(fa0, fb0, 0);
     DMDX_READ_FRAGS(fa0, fb0, cur, 2);
-    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 2 + NI, 0);
     DMDX_KSTEP(fa1, fb1, 1);
     DMDX_READ_FRAGS(fa1, fb1, cur, 3);
-    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 2 + NI, 0);
     DMDX_KSTEP(fa0, fb0, 2);
     DMDX_KSTEP(fa1, fb1, 3);
     if (has_next && !dma_next) stage_regs(c_begin + c + 1, cur ^ 1, c_begin + c + 1 == tail_chunk);
@@ -363,16 +367,16 @@ __global__ __launch_bounds__(NTH, 2) void gemm_tn_partial_kernel(TnParams p) {
       if (c >= FOLD) {
         switch (fq) {
           case 0: DMDX_COMMIT(0, 0, true); break;
-          case 1: DMDX_COMMIT(0, 1, true); break;
+          case 1: if constexpr (NI == 2) { DMDX_COMMIT(0, NI - 1, true); } break;
           case 2: DMDX_COMMIT(1, 0, true); break;
-          default: DMDX_COMMIT(1, 1, true); break;
+          default: if constexpr (NI == 2) { DMDX_COMMIT(1, NI - 1, true); } break;
         }
       } else {
         switch (fq) {
           case 0: DMDX_COMMIT(0, 0, false); break;
-          case 1: DMDX_COMMIT(0, 1, false); break;
+          case 1: if constexpr (NI == 2) { DMDX_COMMIT(0, NI - 1, false); } break;
           case 2: DMDX_COMMIT(1, 0, false); break;
-          default: DMDX_COMMIT(1, 1, false); break;
+          default: if constexpr (NI == 2) { DMDX_COMMIT(1, NI - 1, false); } break;
         }
       }
     }
@@ -380,11 +384,12 @@ __global__ __launch_bounds__(NTH, 2) void gemm_tn_partial_kernel(TnParams p) {
   // final fold of whatever each block still holds (block q was folded before iff the
   // unit ran at least (q+1)*FOLD/4 chunks)
   if (nchunks >= 1 * (FOLD / 4)) { DMDX_PREFETCH(0, 0); DMDX_COMMIT(0, 0, true); } else { DMDX_COMMIT(0, 0, false); }
-  if (nchunks >= 2 * (FOLD / 4)) { DMDX_PREFETCH(0, 1); DMDX_COMMIT(0, 1, true); } else { DMDX_COMMIT(0, 1, false); }
   if (nchunks >= 3 * (FOLD / 4)) { DMDX_PREFETCH(1, 0); DMDX_COMMIT(1, 0, true); } else { DMDX_COMMIT(1, 0, false); }
-  if (nchunks >= 4 * (FOLD / 4)) { DMDX_PREFETCH(1, 1); DMDX_COMMIT(1, 1, true); } else { DMDX_COMMIT(1, 1, false); }
+  if constexpr (NI == 2) {
+    if (nchunks >= 2 * (FOLD / 4)) { DMDX_PREFETCH(0, NI - 1); DMDX_COMMIT(0, NI - 1, true); } else { DMDX_COMMIT(0, NI - 1, false); }
+    if (nchunks >= 4 * (FOLD / 4)) { DMDX_PREFETCH(1, NI - 1); DMDX_COMMIT(1, NI - 1, true); } else { DMDX_COMMIT(1, NI - 1, false); }
+  }
 #undef DMDX_READ_FRAGS
-#undef DMDX_MFMA16
 #undef DMDX_MFMA4
 #undef DMDX_KSTEP
 #undef DMDX_DMA_PAIR
@@ -398,11 +403,13 @@ __global__ __launch_bounds__(NTH, 2) void gemm_tn_partial_kernel(TnParams p) {
 // roles swapped by the host wrapper).  SYRK mode also writes the mirror.
 __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(
     const double* P, int nsplit, int ntiles, int ntr, int ntc, int syrk, int nrow, int ncol,
-    double* D64, int64_t ld64, float* D32, int64_t ld32, int accumulate) {
+    double* D64, int64_t ld64, float* D32, int64_t ld32, int accumulate, int tm) {
   __shared__ double tr[32][33];
-  // one workgroup per (tile, 32x32 sub-block)
-  const int tile = blockIdx.x >> 4;
-  const int sb = blockIdx.x & 15;
+  // one workgroup per (tile, 32x32 sub-block); a tile is tm (64 or 128) rows x 128 columns
+  const int nsb = (tm / 32) * 4;
+  const int tile = blockIdx.x / nsb;
+  const int sb = blockIdx.x - tile * nsb;
+  const int tile_elems = tm * BT;
   int ta, tb;
   if (syrk) {
     decode_tri(tile, ntr, ta, tb);
@@ -415,16 +422,16 @@ __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(
     tb = tt / nrows;
     ta = r0 + tt % nrows;
   }
-  const int row0 = ta * BT, col0 = tb * BT;
+  const int row0 = ta * tm, col0 = tb * BT;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
   const bool diag = syrk && (ta == tb);
   const int si = (sb >> 2) * 32, sj = (sb & 3) * 32;
   if (diag && si > sj) return;  // lower sub-blocks of a diagonal tile: mirrored from the upper ones
   if (row0 + si >= nrow || col0 + sj >= ncol) return;
   double v[4] = {0.0, 0.0, 0.0, 0.0};
-  const double* src = P + (size_t)tile * TILE_ELEMS + (si + ty) * BT + sj + tx;
+  const double* src = P + (size_t)tile * tile_elems + (si + ty) * BT + sj + tx;
   for (int sp = 0; sp < nsplit; ++sp) {
-    const double* q = src + (size_t)sp * ntiles * TILE_ELEMS;
+    const double* q = src + (size_t)sp * ntiles * tile_elems;
 #pragma unroll
     for (int k = 0; k < 4; ++k) v[k] += q[8 * k * BT];
   }
@@ -461,13 +468,15 @@ __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(
 }
 
 struct Plan {
+  int tm;  // tile rows: 128, or 64 when that halves the row padding of a non-SYRK product
   int ntr, ntc, ntiles, nsplit, chunks_total, chunks_per_split;
   size_t ws_bytes;
 };
 
 Plan make_plan(int64_t K, int64_t nrow, int64_t ncol, int syrk) {
   Plan pl;
-  pl.ntr = (int)((nrow + BT - 1) / BT);
+  pl.tm = (!syrk && ((nrow - 1) % BT) < 64) ? 64 : BT;
+  pl.ntr = (int)((nrow + pl.tm - 1) / pl.tm);
   pl.ntc = (int)((ncol + BT - 1) / BT);
   pl.ntiles = syrk ? pl.ntr * (pl.ntr + 1) / 2 : pl.ntr * pl.ntc;
   pl.chunks_total = (int)((K + BK - 1) / BK);
@@ -487,7 +496,7 @@ Plan make_plan(int64_t K, int64_t nrow, int64_t ncol, int syrk) {
   if (want > 256) want = 256;
   pl.chunks_per_split = (int)((pl.chunks_total + want - 1) / want);
   pl.nsplit = (pl.chunks_total + pl.chunks_per_split - 1) / pl.chunks_per_split;
-  pl.ws_bytes = (size_t)pl.nsplit * pl.ntiles * TILE_ELEMS * sizeof(double);
+  pl.ws_bytes = (size_t)pl.nsplit * pl.ntiles * pl.tm * BT * sizeof(double);
   return pl;
 }
 
@@ -510,6 +519,7 @@ int run_tn(const float* A, int64_t lda, const float* B, int64_t ldb, int64_t K, 
   dim3 grid((unsigned)((size_t)pl.nsplit * pl.ntiles));
   int abl = 0;
   if (const char* e = getenv("DMDX_TN_ABLATE")) abl = atoi(e);
+  if (pl.tm != BT) abl = 0;
   if (aligned && abl == 1)
     hipLaunchKernelGGL((gemm_tn_partial_kernel<true, 1>), grid, dim3(NTH), 0, stream, p);
   else if (aligned && abl == 2)
@@ -518,13 +528,18 @@ int run_tn(const float* A, int64_t lda, const float* B, int64_t ldb, int64_t K, 
     hipLaunchKernelGGL((gemm_tn_partial_kernel<true, 8>), grid, dim3(NTH), 0, stream, p);
   else if (aligned && abl == 11)
     hipLaunchKernelGGL((gemm_tn_partial_kernel<true, 11>), grid, dim3(NTH), 0, stream, p);
-  else if (aligned)  // LDS-DMA staging needs 16-byte aligned column starts
+  else if (aligned && pl.tm == 64)  // LDS-DMA staging needs 16-byte aligned column starts
+    hipLaunchKernelGGL((gemm_tn_partial_kernel<true, 0, true>), grid, dim3(NTH), 0, stream, p);
+  else if (aligned)
     hipLaunchKernelGGL(gemm_tn_partial_kernel<true>, grid, dim3(NTH), 0, stream, p);
+  else if (pl.tm == 64)
+    hipLaunchKernelGGL((gemm_tn_partial_kernel<false, 0, true>), grid, dim3(NTH), 0, stream, p);
   else
     hipLaunchKernelGGL(gemm_tn_partial_kernel<false>, grid, dim3(NTH), 0, stream, p);
   DMDX_LAUNCH_CHECK();
-  hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3(pl.ntiles * 16), dim3(256), 0, stream, p.P, pl.nsplit,
-                     pl.ntiles, pl.ntr, pl.ntc, syrk, (int)nrow, (int)ncol, D64, ld64, D32, ld32, accumulate);
+  hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3(pl.ntiles * (pl.tm / 32) * 4), dim3(256), 0, stream, p.P,
+                     pl.nsplit, pl.ntiles, pl.ntr, pl.ntc, syrk, (int)nrow, (int)ncol, D64, ld64, D32, ld32,
+                     accumulate, pl.tm);
   DMDX_LAUNCH_CHECK();
   return 0;
 }

@@ -85,7 +85,8 @@ def test_syrk_large_properties(K):
 
 
 # ---------------------------------------------------------------- K3 GEMM_TN
-@pytest.mark.parametrize("K_,na,nb", [(64, 3, 2), (1000, 130, 60), (4097, 300, 70), (50000, 192, 220)])
+@pytest.mark.parametrize("K_,na,nb", [(64, 3, 2), (1000, 130, 60), (4097, 300, 70), (50000, 192, 220),
+                                       (3001, 257, 33), (20000, 140, 150), (777, 64, 64), (5000, 1000, 129)])
 def test_gemm_tn(K, K_, na, nb):
     rs = np.random.RandomState(K_ + na + nb)
     A = _rand(rs, K_, na)

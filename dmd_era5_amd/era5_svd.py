@@ -243,25 +243,43 @@ def _upload_variable(da: DataArray, level_idx, take, device, kern, center, scale
     contiguous = np.array_equal(take, np.arange(take[0], take[0] + n)) if n else True
     all_levels = len(level_idx) == nlev_all and np.array_equal(level_idx, np.arange(nlev_all))
     nbytes = 0
-    for j0 in range(0, n, rows):
+    # fast path: fp32 file-backed variable, contiguous snapshots, every level: the slab is read
+    # straight into one of two pinned staging buffers and copied to the device asynchronously,
+    # so the next read overlaps the previous host->device copy
+    direct = lazy is not None and contiguous and all_levels and lazy.dtype == np.float32
+    pinned = [torch.empty((rows, m_v), dtype=torch.float32).pin_memory() for _ in range(2)] if direct else None
+    events = [None, None]
+    for it, j0 in enumerate(range(0, n, rows)):
         j1 = min(n, j0 + rows)
-        if contiguous:
-            t0, t1 = int(take[j0]), int(take[j1 - 1]) + 1
-            slab = lazy.read_slab(t0, t1) if lazy is not None else host[t0:t1]
-        else:  # resampled: gather the selected snapshots
-            idx = take[j0:j1]
-            if lazy is not None:
-                lo, hi = int(idx.min()), int(idx.max()) + 1
-                slab = lazy.read_slab(lo, hi)[idx - lo]
-            else:
-                slab = host[idx]
-        if not all_levels:
-            slab = slab[:, level_idx]
-        slab = np.ascontiguousarray(slab.reshape(j1 - j0, m_v), dtype=np.float32)
-        nbytes += slab.nbytes
-        dev = torch.from_numpy(slab).to(device, non_blocking=False)
+        if direct:
+            buf = pinned[it & 1]
+            if events[it & 1] is not None:
+                events[it & 1].synchronize()        # the copy that last used this buffer is done
+            view = buf[: j1 - j0].numpy().reshape((j1 - j0,) + tuple(lazy.shape[1:]))
+            lazy.read_slab(int(take[j0]), int(take[j1 - 1]) + 1, view)
+            dev = buf[: j1 - j0].to(device, non_blocking=True)
+            nbytes += (j1 - j0) * m_v * 4
+        else:
+            if contiguous:
+                t0, t1 = int(take[j0]), int(take[j1 - 1]) + 1
+                slab = lazy.read_slab(t0, t1) if lazy is not None else host[t0:t1]
+            else:  # resampled: gather the selected snapshots
+                idx = take[j0:j1]
+                if lazy is not None:
+                    lo, hi = int(idx.min()), int(idx.max()) + 1
+                    slab = lazy.read_slab(lo, hi)[idx - lo]
+                else:
+                    slab = host[idx]
+            if not all_levels:
+                slab = slab[:, level_idx]
+            slab = np.ascontiguousarray(slab.reshape(j1 - j0, m_v), dtype=np.float32)
+            nbytes += slab.nbytes
+            dev = torch.from_numpy(slab).to(device, non_blocking=False)
         for (a, b), Xb in zip(ranges, blocks):
             Xb[j0:j1].copy_(dev[:, a:b])
+        if direct:
+            events[it & 1] = torch.cuda.Event()
+            events[it & 1].record()
         del dev
     for Xb in blocks:
         if center:

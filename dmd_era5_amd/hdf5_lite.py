@@ -390,12 +390,14 @@ class Reader:
         shape, dt, _ = self.variables[name]
         return self._read(name, shape, dt, None)
 
-    def read_slab(self, name: str, start: int, stop: int) -> np.ndarray:
-        """Rows [start, stop) along the first dimension (time slab of an ERA5 variable)."""
+    def read_slab(self, name: str, start: int, stop: int, out: np.ndarray | None = None) -> np.ndarray:
+        """Rows [start, stop) along the first dimension (time slab of an ERA5 variable).
+        ``out``: a C-contiguous array of the slab's shape and the file's dtype to read into
+        (e.g. a view of a pinned staging buffer)."""
         shape, dt, _ = self.variables[name]
-        return self._read(name, (stop - start,) + shape[1:], dt, (start, stop))
+        return self._read(name, (stop - start,) + shape[1:], dt, (start, stop), out)
 
-    def _read(self, name, shape, dt, rng):
+    def _read(self, name, shape, dt, rng, out_buf=None):
         lib = self.lib
         did = lib.H5Dopen2(self.fid, name.encode(), _H5P_DEFAULT)
         fsp, msp = _H5S_ALL, _H5S_ALL
@@ -419,7 +421,12 @@ class Reader:
                 lib.H5Sclose(sp)
                 lib.H5Tclose(tid)
                 return out
-            out = np.empty(shape, dtype=dt)
+            if out_buf is not None and not isinstance(dt, str) and dt.kind != "S":
+                if out_buf.shape != tuple(shape) or out_buf.dtype != dt or not out_buf.flags.c_contiguous:
+                    raise ValueError("read_slab: out must be C-contiguous with the slab's shape and dtype")
+                out = out_buf
+            else:
+                out = np.empty(shape, dtype=dt)
             if dt.kind == "S":
                 tid = lib.H5Dget_type(did)
                 rc = lib.H5Dread(did, tid, msp, fsp, _H5P_DEFAULT, out.ctypes.data_as(C.c_void_p))

@@ -1,0 +1,39 @@
+"""Scratch: file -> HBM ingest rate of main() (HDF5/NETCDF4 slice, lazy time slabs, K5 on device),
+i.e. the PCIe-inclusive side of the path that bench.py's `value` leaves out."""
+import os, sys, time, tempfile
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+root = tempfile.mkdtemp(prefix="dmdx_ingest_")
+os.environ["DMD_ERA5_ROOT"] = root
+os.environ["DMDX_NETCDF_BACKEND"] = "hdf5"
+from dmd_era5_amd import io_netcdf, hdf5_lite
+from dmd_era5_amd.config_parser import config_parser
+from dmd_era5_amd.era5_svd import main
+
+cfg = {"source_path": "synthetic", "variables": "temperature", "levels": "1000",
+       "svd_type": "standard", "delay_embedding": 2, "mean_center": True, "scale": False,
+       "start_datetime": "2019-01-01T00", "end_datetime": "2019-02-11T15", "delta_time": "1h",
+       "n_components": 20, "save_data_matrix": False}
+p = config_parser(cfg, "era5-svd")
+n, nlat, nlon = 1000, 721, 1440            # 1000 hourly 0.25-degree fields = 4.15 GB
+os.makedirs(os.path.dirname(p["era5_slice_path"]), exist_ok=True)
+rs = np.random.RandomState(0)
+t0 = time.perf_counter()
+with hdf5_lite.Writer(p["era5_slice_path"]) as w:
+    times = (np.datetime64("2019-01-01T00", "ns") + np.arange(n) * np.timedelta64(1, "h"))
+    hours = ((times - np.datetime64("1970-01-01T00", "ns")) / np.timedelta64(1, "h")).astype(np.int64)
+    w.dataset("time", hours, ("time",), {"units": io_netcdf.TIME_UNITS, "calendar": "proleptic_gregorian"})
+    w.dataset("level", np.array([1000], dtype=np.int64), ("level",))
+    w.dataset("latitude", np.linspace(90, -90, nlat), ("latitude",))
+    w.dataset("longitude", np.linspace(0, 359.75, nlon), ("longitude",))
+    base = rs.standard_normal((8, nlat * nlon)).astype(np.float32)
+    coef = rs.standard_normal((n, 8)).astype(np.float32) * (0.8 ** np.arange(8, dtype=np.float32))
+    field = (coef @ base + 280).reshape(n, 1, nlat, nlon)
+    w.dataset("temperature", field, ("time", "level", "latitude", "longitude"))
+    w.attrs(None, {"source_path": "synthetic", "variables": ["temperature"], "levels": [1000]})
+print(f"wrote {os.path.getsize(p['era5_slice_path'])/1e9:.2f} GB slice in {time.perf_counter()-t0:.1f} s", flush=True)
+del field
+t0 = time.perf_counter()
+res, _, _ = main(cfg, write_to_netcdf=True)
+print(f"main(): {time.perf_counter()-t0:.2f} s total; s head {res['s'].values[:3]}", flush=True)
+print("result file:", os.path.getsize(p["save_path"]) / 1e6, "MB")

@@ -139,3 +139,24 @@ def test_main_streams_a_lazy_hdf5_slice_with_resampling(svd_base_config, project
     back = io_netcdf.open_dataset(p["save_path"])
     assert np.allclose(back["s"].values, res["s"].values)
     assert list(np.unique(back.coords["original_variable"].values)) == ["temperature", "v_component_of_wind"]
+
+
+def test_main_direct_pinned_ingest_path(svd_base_config, project_root, monkeypatch):
+    """fp32 file-backed variable, hourly (contiguous) snapshots, all levels: slabs are read straight
+    into pinned staging buffers and copied asynchronously -- same X as the oracle."""
+    from dmd_era5_amd import era5_svd, io_netcdf
+    from dmd_era5_amd.era5_svd import main
+
+    monkeypatch.setenv("DMDX_NETCDF_BACKEND", "hdf5")
+    monkeypatch.setattr(io_netcdf, "LAZY_BYTES", 1000)
+    monkeypatch.setattr(era5_svd, "SLAB_BYTES", 5 * 2 * 36 * 72 * 4)      # 5 snapshots per slab, 2 buffers
+    cfg = dict(svd_base_config, start_datetime="2019-01-01T00", end_datetime="2019-01-02T12",
+               variables="temperature", levels="1000,850", svd_type="standard", mean_center=True,
+               scale=True, delay_embedding=1, n_components=4, save_data_matrix=True)
+    p, ds = _write_slice(cfg, seed=12, dtype=np.float32)
+    res, _, _ = main(cfg)
+    X, _, _ = orc.preprocess({"temperature": ds["temperature"].values}, True, True, 1)
+    assert res["X"].shape == X.shape == (2 * 36 * 72, 37)
+    assert np.allclose(res["X"].values, X, rtol=0, atol=2e-4)
+    _, so, _ = orc.svd_standard(X.astype(np.float64), 4)
+    assert np.allclose(res["s"].values, so, rtol=2e-5)

@@ -32,7 +32,7 @@ namespace {
 
 constexpr int BT = 128;            // output tile edge
 constexpr int BK = 32;             // K rows per stage
-constexpr int FOLD = 128;          // chunks per fp32 chain (128 * 32 = 4096 rows) before the fp64 fold
+constexpr int FOLD = 128;          // chunks per fp32 chain (128 * 32 = 4096 rows) before it is folded into acc2
 constexpr int NTH = 256;
 // fp32 chain length = 32 chunks * 32 rows = 1024 rows (hard-wired in the fold schedule)
 
@@ -108,6 +108,21 @@ __device__ inline f32x4 load4_tail(const float* p, int64_t k, int64_t kend) {
   return v;
 }
 
+#ifdef DMDX_STAMPS
+// diagnostic build only (make stamps): per-segment cycle totals of the chunk loop, summed over
+// all waves: [0] DMA issue, [1] fragment reads + MFMA issue, [5] wait for the LDS-DMA (vmcnt),
+// [2] barrier, [3] post-barrier (first fragment read, fold), [4] chunks counted
+__device__ unsigned long long dmdx_stamp[8];
+#define DMDX_STAMP(var)                                                        \
+  do {                                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                         \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory"); \
+    __builtin_amdgcn_sched_barrier(0);                                         \
+  } while (0)
+#else
+#define DMDX_STAMP(var) do { } while (0)
+#endif
+
 #define DMDX_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 #define DMDX_GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 
@@ -161,7 +176,8 @@ __global__ __launch_bounds__(NTH, 2) void gemm_tn_partial_kernel(TnParams p) {
   // Register path: thread -> column (tid >> 3) + 32 i, k-chunk (tid & 7).
   // addresses = wave-uniform tile base (SGPRs, advanced along K) + 32-bit per-lane element
   // offset: the LDS-DMA then needs no per-instruction 64-bit VALU add
-  const int ra0 = row0 < p.nrow ? row0 : p.nrow - 1, cb0 = col0 < p.ncol ? col0 : p.ncol - 1;
+  const int ra0 = row0 < p.nrow ? row0 : p.nrow - 1;
+  const int cb0 = col0 < p.ncol ? col0 : p.ncol - 1;
   const float* Abase = p.A + (int64_t)ra0 * p.lda;
   const float* Bbase = p.B + (int64_t)cb0 * p.ldb;
   unsigned aoff[NPA], boff[4];
@@ -188,6 +204,19 @@ __global__ __launch_bounds__(NTH, 2) void gemm_tn_partial_kernel(TnParams p) {
     kqa[i] = 4 * q;
   }
 
+  // LDS-DMA addressing: wave-uniform byte pointer (SGPR pair, advanced along K) + 32-bit
+  // per-lane BYTE offset, the `saddr` form of global_load_lds -- no VALU work per piece.
+  // Piece i of an operand lands at LDS base (M0) + 1024 i through the instruction's immediate
+  // offset, which the hardware adds to the global address too: offsets carry + 3072 - 1024 i
+  // and the base pointer - 3072, so that every offset stays non-negative.
+  const char* Adma = reinterpret_cast<const char*>(Abase) - 3072;
+  const char* Bdma = reinterpret_cast<const char*>(Bbase) - 3072;
+  unsigned aoffb[NPA], boffb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) boffb[i] = 4u * boff[i] + 3072u - 1024u * i;
+#pragma unroll
+  for (int i = 0; i < NPA; ++i) aoffb[i] = 4u * aoff[i] + 3072u - 1024u * i;
+
   f32x16 acc[2][NI];
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi)
@@ -196,43 +225,49 @@ __global__ __launch_bounds__(NTH, 2) void gemm_tn_partial_kernel(TnParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-  // ---- fp64 partial tile of this unit (owned: only this workgroup touches it).
-  // Block q = (mi, ni) of the wave is folded into it every FOLD chunks (fp32 chains of
-  // FOLD*32 rows), the four blocks staggered by FOLD/4 chunks so that at most one
-  // block's 16 old values are in flight (prefetched one chunk ahead of the fold).
-  // The partial tile is streamed (non-temporal): it is touched once per FOLD chunks.
+  // ---- two-level fp32 accumulation inside a unit, fp64 across units.
+  // acc holds fp32 chains of at most FOLD*32 = 4096 rows.  Every FOLD chunks block
+  // q = (mi, ni) of the wave is added into acc2 (registers) and cleared; the four blocks
+  // are staggered by FOLD/4 chunks.  A unit runs <= max_cps chunks, so acc2 sums <= 8
+  // chain results: the rounding error stays that of a 4096-row fp32 chain (blocked
+  // summation), and the loop touches no memory except the operand stream.  (Folding
+  // into an fp64 tile in HBM instead cost 4.6 % -- ~115 VALU/VMEM instructions per fold,
+  // each of which waits for an MFMA slot while the SIMD's other wave streams MFMAs.)
+  // At the end of the unit acc + acc2 is stored once, as fp64, into the unit's partial tile.
+  f32x16 acc2[2][NI];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc2[mi][ni][r] = 0.f;
   double* Pt = p.P + ((size_t)split * p.ntiles + tile) * (TM * BT);
   const int lane_off = (64 * wr + 4 * lh) * BT + (SK ? 32 : 64) * wc + l31;
-  double oldv[16];
 #define DMDX_BLOCK_OFF(mi, ni, r) ((32 * (mi) + ((r) & 3) + 8 * ((r) >> 2)) * BT + 32 * (ni))
-#define DMDX_PREFETCH(mi, ni)                                                     \
+#define DMDX_FOLD(mi, ni)                                                         \
   do {                                                                            \
-    int lo_ = lane_off;                                                           \
-    asm volatile("" : "+v"(lo_)); /* keep the 16 addresses out of loop-invariant hoisting */ \
-    const double* q_ = Pt + lo_;                                                  \
-    _Pragma("unroll") for (int r = 0; r < 16; ++r)                                \
-        oldv[r] = __builtin_nontemporal_load(q_ + DMDX_BLOCK_OFF(mi, ni, r));     \
+    acc2[mi][ni] += acc[mi][ni];                                                  \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;          \
   } while (0)
-#define DMDX_COMMIT(mi, ni, have_old)                                             \
+#define DMDX_COMMIT(mi, ni)                                                       \
   do {                                                                            \
-    int lo_ = lane_off;                                                           \
-    asm volatile("" : "+v"(lo_));                                                 \
-    double* q_ = Pt + lo_;                                                        \
-    _Pragma("unroll") for (int r = 0; r < 16; ++r) {                              \
-      double v_ = (double)acc[mi][ni][r];                                         \
-      if (have_old) v_ += oldv[r];                                                \
-      __builtin_nontemporal_store(v_, q_ + DMDX_BLOCK_OFF(mi, ni, r));            \
-      acc[mi][ni][r] = 0.f;                                                       \
+    double* q_ = Pt + lane_off;                                                   \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r)                                \
+        __builtin_nontemporal_store((double)(acc[mi][ni][r] + acc2[mi][ni][r]),   \
+                                    q_ + DMDX_BLOCK_OFF(mi, ni, r));              \
+  } while (0)
+#define DMDX_COMMIT_ALL()                                                         \
+  do {                                                                            \
+    DMDX_COMMIT(0, 0);                                                            \
+    DMDX_COMMIT(1, 0);                                                            \
+    if constexpr (NI == 2) {                                                      \
+      DMDX_COMMIT(0, NI - 1);                                                     \
+      DMDX_COMMIT(1, NI - 1);                                                     \
     }                                                                             \
   } while (0)
 
   if (nchunks <= 0) {  // empty split: the partial tile must still be defined
-    DMDX_COMMIT(0, 0, false);
-    DMDX_COMMIT(1, 0, false);
-    if constexpr (NI == 2) {
-      DMDX_COMMIT(0, 1, false);
-      DMDX_COMMIT(1, 1, false);
-    }
+    DMDX_COMMIT_ALL();
     return;
   }
 
@@ -257,16 +292,47 @@ __global__ __launch_bounds__(NTH, 2) void gemm_tn_partial_kernel(TnParams p) {
 #pragma unroll
     for (int i = 0; i < NPA; ++i) *reinterpret_cast<f32x4*>(as + stsa[i]) = ra[i];
   };
+// The 8 pieces of the next chunk in one asm block: 2 SALU (M0) + 8 VMEM, no VALU.  A wave
+// whose SIMD partner streams MFMAs gets ~one instruction issued per MFMA slot (stamps:
+// ~64-95 cycles each), so every VALU address add in this phase cost a whole MFMA slot.
+#define DMDX_DMA_NEXT(ap, bp, la, lb)                                                              \
+  do {                                                                                             \
+    if constexpr (NPA == 4)                                                                        \
+      asm volatile("s_mov_b32 m0, %[la_]\n\ts_nop 0\n\t"                                           \
+                   "global_load_lds_dwordx4 %[a0], %[ap_]\n\t"                                     \
+                   "global_load_lds_dwordx4 %[a1], %[ap_] offset:1024\n\t"                         \
+                   "global_load_lds_dwordx4 %[a2], %[ap_] offset:2048\n\t"                         \
+                   "global_load_lds_dwordx4 %[a3], %[ap_] offset:3072\n\t"                         \
+                   "s_mov_b32 m0, %[lb_]\n\ts_nop 0\n\t"                                           \
+                   "global_load_lds_dwordx4 %[b0], %[bp_]\n\t"                                     \
+                   "global_load_lds_dwordx4 %[b1], %[bp_] offset:1024\n\t"                         \
+                   "global_load_lds_dwordx4 %[b2], %[bp_] offset:2048\n\t"                         \
+                   "global_load_lds_dwordx4 %[b3], %[bp_] offset:3072"                             \
+                   :: [la_] "s"(la), [lb_] "s"(lb), [ap_] "s"(ap), [bp_] "s"(bp),                   \
+                      [a0] "v"(aoffb[0]), [a1] "v"(aoffb[1]), [a2] "v"(aoffb[NPA - 2]),            \
+                      [a3] "v"(aoffb[NPA - 1]), [b0] "v"(boffb[0]), [b1] "v"(boffb[1]),            \
+                      [b2] "v"(boffb[2]), [b3] "v"(boffb[3])                                       \
+                   : "memory");                                                                    \
+    else                                                                                           \
+      asm volatile("s_mov_b32 m0, %[la_]\n\ts_nop 0\n\t"                                           \
+                   "global_load_lds_dwordx4 %[a0], %[ap_]\n\t"                                     \
+                   "global_load_lds_dwordx4 %[a1], %[ap_] offset:1024\n\t"                         \
+                   "s_mov_b32 m0, %[lb_]\n\ts_nop 0\n\t"                                           \
+                   "global_load_lds_dwordx4 %[b0], %[bp_]\n\t"                                     \
+                   "global_load_lds_dwordx4 %[b1], %[bp_] offset:1024\n\t"                         \
+                   "global_load_lds_dwordx4 %[b2], %[bp_] offset:2048\n\t"                         \
+                   "global_load_lds_dwordx4 %[b3], %[bp_] offset:3072"                             \
+                   :: [la_] "s"(la), [lb_] "s"(lb), [ap_] "s"(ap), [bp_] "s"(bp),                   \
+                      [a0] "v"(aoffb[0]), [a1] "v"(aoffb[1]), [b0] "v"(boffb[0]),                  \
+                      [b1] "v"(boffb[1]), [b2] "v"(boffb[2]), [b3] "v"(boffb[3])                   \
+                   : "memory");                                                                    \
+  } while (0)
   auto stage_dma = [&](int chunk, int st) {
     const int64_t k0 = (int64_t)chunk * BK;
     float* as = lds + st * STG + ((TM / 4) * wave) * BK;
     float* bs = lds + st * STG + OPA + (32 * wave) * BK;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      if (i < NPA)
-        __builtin_amdgcn_global_load_lds(DMDX_GLB_PTR(Abase + k0 + aoff[i < NPA ? i : 0]), DMDX_LDS_PTR(as + 8 * i * BK), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds(DMDX_GLB_PTR(Bbase + k0 + boff[i]), DMDX_LDS_PTR(bs + 8 * i * BK), 16, 0, 0);
-    }
+    DMDX_DMA_NEXT(Adma + 4 * k0, Bdma + 4 * k0, (unsigned)(uintptr_t)DMDX_LDS_PTR(as),
+                  (unsigned)(uintptr_t)DMDX_LDS_PTR(bs));
   };
   auto stage = [&](int chunk, int st) {
     if (DMA) {
@@ -296,21 +362,12 @@ __global__ __launch_bounds__(NTH, 2) void gemm_tn_partial_kernel(TnParams p) {
   } while (0)
 
   stage(c_begin, 0);
+  if (DMA) __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0), see the main loop
   __syncthreads();
   DMDX_READ_FRAGS(fa0, fb0, 0, 0);
 
   // DMA pair i = pieces i of A and B of the next chunk.  (Issuing the pairs between the
   // MFMAs of the k-steps instead of up front measured 1-2 % slower.)
-#define DMDX_DMA_PAIR(i)                                                                          \
-  do {                                                                                            \
-    if (dma_next) {                                                                               \
-      if constexpr ((i) < NPA)                                                                    \
-        __builtin_amdgcn_global_load_lds(DMDX_GLB_PTR(Abase + knext + aoff[(i) < NPA ? (i) : 0]), \
-                                         DMDX_LDS_PTR(dma_as + 8 * (i) * BK), 16, 0, 0);          \
-      __builtin_amdgcn_global_load_lds(DMDX_GLB_PTR(Bbase + knext + boff[i]),                     \
-                                       DMDX_LDS_PTR(dma_bs + 8 * (i) * BK), 16, 0, 0);            \
-    }                                                                                             \
-  } while (0)
 #define DMDX_MFMA4(FA, FB, j)                                                                   \
   do {                                                                                          \
     _Pragma("unroll") for (int mi_ = 0; mi_ < 2; ++mi_)                                         \
@@ -327,27 +384,23 @@ __global__ __launch_bounds__(NTH, 2) void gemm_tn_partial_kernel(TnParams p) {
     __builtin_amdgcn_sched_group_barrier(0x008, 8 * NI, 0);        \
   } while (0)
 
+#ifdef DMDX_STAMPS
+  unsigned long long st0 = 0, st1 = 0, st2 = 0, st2b = 0, st3 = 0, st4 = 0, sa0 = 0, sa1 = 0, sa2 = 0, sa3 = 0, sa5 = 0;
+#endif
   int cur = 0;
   for (int c = 0; c < nchunks; ++c) {
+    DMDX_STAMP(st0);
     const bool has_next = (c + 1 < nchunks) && !(ABL & 1);
     const bool dma_next = DMA && has_next && (c_begin + c + 1 != tail_chunk);
     const int64_t knext = (int64_t)(c_begin + c + 1) * BK;
     float* dma_as = lds + (cur ^ 1) * STG + ((TM / 4) * wave) * BK;
     float* dma_bs = lds + (cur ^ 1) * STG + OPA + (32 * wave) * BK;
     const int phase = c & (FOLD / 4 - 1), fq = (c / (FOLD / 4)) & 3;
-    if (!(ABL & 8) && phase == FOLD / 4 - 2 && c >= FOLD) {  // old partial values of block fq, used one chunk later
-      switch (fq) {
-        case 0: DMDX_PREFETCH(0, 0); break;
-        case 1: if constexpr (NI == 2) { DMDX_PREFETCH(0, NI - 1); } break;
-        case 2: DMDX_PREFETCH(1, 0); break;
-        default: if constexpr (NI == 2) { DMDX_PREFETCH(1, NI - 1); } break;
-      }
+    if (dma_next) {  // all pieces of one operand share one M0 value (see stage_dma)
+      DMDX_DMA_NEXT(Adma + 4 * knext, Bdma + 4 * knext,
+                    (unsigned)(uintptr_t)DMDX_LDS_PTR(dma_as), (unsigned)(uintptr_t)DMDX_LDS_PTR(dma_bs));
     }
-
-    DMDX_DMA_PAIR(0);
-    DMDX_DMA_PAIR(1);
-    DMDX_DMA_PAIR(2);
-    DMDX_DMA_PAIR(3);
+    DMDX_STAMP(st1);
     DMDX_READ_FRAGS(fa1, fb1, cur, 1);
     __builtin_amdgcn_sched_group_barrier(0x100, 2 + NI, 0);   // ds_reads of the next fragments
     DMDX_KSTEP(fa0, fb0, 0);
@@ -358,42 +411,43 @@ __global__ __launch_bounds__(NTH, 2) void gemm_tn_partial_kernel(TnParams p) {
     __builtin_amdgcn_sched_group_barrier(0x100, 2 + NI, 0);
     DMDX_KSTEP(fa0, fb0, 2);
     DMDX_KSTEP(fa1, fb1, 3);
+    DMDX_STAMP(st2);
     if (has_next && !dma_next) stage_regs(c_begin + c + 1, cur ^ 1, c_begin + c + 1 == tail_chunk);
 
+    if (DMA) __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): the asm LDS-DMA pieces are invisible to the compiler's counters
+    DMDX_STAMP(st2b);
     if (!(ABL & 2)) __syncthreads();  // waits for this wave's LDS-DMA (vmcnt) and for every wave's reads of `cur`
     cur ^= 1;
+    DMDX_STAMP(st3);
     if (has_next) DMDX_READ_FRAGS(fa0, fb0, cur, 0);
     if (!(ABL & 8) && phase == FOLD / 4 - 1) {
-      if (c >= FOLD) {
-        switch (fq) {
-          case 0: DMDX_COMMIT(0, 0, true); break;
-          case 1: if constexpr (NI == 2) { DMDX_COMMIT(0, NI - 1, true); } break;
-          case 2: DMDX_COMMIT(1, 0, true); break;
-          default: if constexpr (NI == 2) { DMDX_COMMIT(1, NI - 1, true); } break;
-        }
-      } else {
-        switch (fq) {
-          case 0: DMDX_COMMIT(0, 0, false); break;
-          case 1: if constexpr (NI == 2) { DMDX_COMMIT(0, NI - 1, false); } break;
-          case 2: DMDX_COMMIT(1, 0, false); break;
-          default: if constexpr (NI == 2) { DMDX_COMMIT(1, NI - 1, false); } break;
-        }
+      switch (fq) {
+        case 0: DMDX_FOLD(0, 0); break;
+        case 1: if constexpr (NI == 2) { DMDX_FOLD(0, NI - 1); } break;
+        case 2: DMDX_FOLD(1, 0); break;
+        default: if constexpr (NI == 2) { DMDX_FOLD(1, NI - 1); } break;
       }
     }
+#ifdef DMDX_STAMPS
+    DMDX_STAMP(st4);
+    sa0 += st1 - st0; sa1 += st2 - st1; sa2 += st3 - st2b; sa3 += st4 - st3; sa5 += st2b - st2;
+#endif
   }
-  // final fold of whatever each block still holds (block q was folded before iff the
-  // unit ran at least (q+1)*FOLD/4 chunks)
-  if (nchunks >= 1 * (FOLD / 4)) { DMDX_PREFETCH(0, 0); DMDX_COMMIT(0, 0, true); } else { DMDX_COMMIT(0, 0, false); }
-  if (nchunks >= 3 * (FOLD / 4)) { DMDX_PREFETCH(1, 0); DMDX_COMMIT(1, 0, true); } else { DMDX_COMMIT(1, 0, false); }
-  if constexpr (NI == 2) {
-    if (nchunks >= 2 * (FOLD / 4)) { DMDX_PREFETCH(0, NI - 1); DMDX_COMMIT(0, NI - 1, true); } else { DMDX_COMMIT(0, NI - 1, false); }
-    if (nchunks >= 4 * (FOLD / 4)) { DMDX_PREFETCH(1, NI - 1); DMDX_COMMIT(1, NI - 1, true); } else { DMDX_COMMIT(1, NI - 1, false); }
+#ifdef DMDX_STAMPS
+  if (lane == 0) {
+    atomicAdd(&dmdx_stamp[0], sa0); atomicAdd(&dmdx_stamp[1], sa1);
+    atomicAdd(&dmdx_stamp[2], sa2); atomicAdd(&dmdx_stamp[3], sa3);
+    atomicAdd(&dmdx_stamp[5], sa5);
+    atomicAdd(&dmdx_stamp[4], (unsigned long long)nchunks);
   }
+#endif
+  DMDX_COMMIT_ALL();
 #undef DMDX_READ_FRAGS
 #undef DMDX_MFMA4
 #undef DMDX_KSTEP
-#undef DMDX_DMA_PAIR
-#undef DMDX_PREFETCH
+#undef DMDX_DMA_NEXT
+#undef DMDX_FOLD
+#undef DMDX_COMMIT_ALL
 #undef DMDX_COMMIT
 #undef DMDX_BLOCK_OFF
 }
@@ -515,7 +569,14 @@ int run_tn(const float* A, int64_t lda, const float* B, int64_t ldb, int64_t K, 
   p.nsplit = pl.nsplit; p.chunks_total = pl.chunks_total;
   p.chunks_per_split = pl.chunks_per_split;
   p.P = reinterpret_cast<double*>(ws);
-  const bool aligned = (lda % 4 == 0) && (ldb % 4 == 0) && dmdx_aligned16(A) && dmdx_aligned16(B);
+  // per-lane offsets inside a 128-column panel are 32-bit: elements on the register path,
+  // bytes (+ 4 KiB of slack) on the LDS-DMA path
+  if (lda >= (int64_t(1) << 25) || ldb >= (int64_t(1) << 25)) {
+    dmdx_set_error("gemm_tn: leading dimension %lld / %lld >= 2^25 not supported", (long long)lda, (long long)ldb);
+    return DMDX_E_UNSUPPORTED;
+  }
+  const bool aligned = (lda % 4 == 0) && (ldb % 4 == 0) && dmdx_aligned16(A) && dmdx_aligned16(B) &&
+                       lda < (int64_t(1) << 22) && ldb < (int64_t(1) << 22);
   dim3 grid((unsigned)((size_t)pl.nsplit * pl.ntiles));
   int abl = 0;
   if (const char* e = getenv("DMDX_TN_ABLATE")) abl = atoi(e);
@@ -547,6 +608,17 @@ int run_tn(const float* A, int64_t lda, const float* B, int64_t ldb, int64_t K, 
 }  // namespace
 
 extern "C" {
+
+#ifdef DMDX_STAMPS
+int dmdx_debug_read_stamps(unsigned long long* out8, int reset) {
+  hipError_t e = hipMemcpyFromSymbol(out8, HIP_SYMBOL(dmdx_stamp), 8 * sizeof(unsigned long long));
+  if (reset) {
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(dmdx_stamp), z, sizeof(z));
+  }
+  return (int)e;
+}
+#endif
 
 size_t dmdx_syrk_workspace_bytes(int64_t m, int64_t n) {
   if (m < 0 || n <= 0) return 0;

@@ -6,17 +6,23 @@
 //   work unit = (K-split s, 128x128 output tile t); one 256-thread workgroup
 //   (4 waves, 2x2, each wave a 64x64 sub-tile = 2x2 MFMA blocks of 32x32) per
 //   unit, two workgroups resident per CU.
-//   K loop: 32-row chunks, register-staged global -> LDS double buffer
-//   (global_load_dwordx4 along K, which is the contiguous axis of both
-//   operands; LDS rows padded to 36 floats so the ds_read_b128 fragment reads
-//   are bank-conflict free).  One ds_read_b128 per operand block feeds four
-//   MFMAs: lane (r, h) reads k = 8t+4h .. 8t+4h+3 of its row, MFMA j uses
+//   K loop: 32-row chunks through two LDS stages.  Aligned operands are staged by
+//   LDS-DMA (global_load_lds_dwordx4 along K, the contiguous axis of both
+//   operands; SGPR base + 32-bit per-lane byte offset, no VALU per piece); the LDS
+//   panels are unpadded [column][32 k] with the 16-byte k-chunks XOR-swizzled by
+//   (column >> 1) & 7 on the DMA source and on the fragment reads, which makes the
+//   ds_read_b128 fragment reads bank-conflict free.  Unaligned operands and the
+//   K tail go through registers.  One ds_read_b128 per operand block feeds four
+//   MFMAs: lane (r, h) reads k = 8t+4h .. 8t+4h+3 of its column, MFMA j uses
 //   element j of both operands -- the same k permutation on both sides, so
 //   the contraction is unchanged.
-//   Numerics: fp32 MFMA chains of at most 32 chunks * 32 = 1024 rows, then the
-//   chain is added in fp64 into the unit's own partial tile in HBM (owned
-//   read-modify-write, no atomics => deterministic); a second kernel sums the
-//   K-splits in fp64 and writes D (both triangles in SYRK mode).
+//   Numerics: fp32 MFMA chains of at most 128 chunks * 32 = 4096 rows; the chain
+//   results of a unit (at most 8) are summed in a second fp32 register
+//   accumulator (blocked summation: the error bound stays that of a 4096-row
+//   chain) and stored once, as fp64, into the unit's own partial tile (no
+//   atomics => deterministic); a second kernel sums the K-splits in fp64 and
+//   writes D (both triangles in SYRK mode).  Row blocks are accumulated into D
+//   in fp64 (`accumulate`).
 //
 // L2 locality: units are ordered tile-fastest inside a K-split, the tiles of
 // the triangle are enumerated in 4-row super-rows, column by column, so 32
@@ -34,7 +40,6 @@ constexpr int BT = 128;            // output tile edge
 constexpr int BK = 32;             // K rows per stage
 constexpr int FOLD = 128;          // chunks per fp32 chain (128 * 32 = 4096 rows) before it is folded into acc2
 constexpr int NTH = 256;
-// fp32 chain length = 32 chunks * 32 rows = 1024 rows (hard-wired in the fold schedule)
 
 struct TnParams {
   const float* A;   // MFMA "A" operand source: D rows
@@ -111,7 +116,8 @@ __device__ inline f32x4 load4_tail(const float* p, int64_t k, int64_t kend) {
 #ifdef DMDX_STAMPS
 // diagnostic build only (make stamps): per-segment cycle totals of the chunk loop, summed over
 // all waves: [0] DMA issue, [1] fragment reads + MFMA issue, [5] wait for the LDS-DMA (vmcnt),
-// [2] barrier, [3] post-barrier (first fragment read, fold), [4] chunks counted
+// [2] barrier, [3] post-barrier (first fragment read, fold), [4] chunks counted,
+// [6] / [7] chunk-loop time in core cycles / in 100 MHz ticks (their ratio = sustained clock)
 __device__ unsigned long long dmdx_stamp[8];
 #define DMDX_STAMP(var)                                                        \
   do {                                                                         \
@@ -130,7 +136,7 @@ __device__ unsigned long long dmdx_stamp[8];
 //              bases and leading dimensions); the K-tail chunk goes through registers.
 // DMA = false: everything register-staged with scalar loads (any alignment).
 // ABL: timing-only ablations for diagnosis (results are wrong when ABL != 0):
-//   1 no global->LDS staging, 2 no barrier, 8 no fp64 fold (none of them changes an address).  Selected by DMDX_TN_ABLATE.
+//   1 no global->LDS staging, 2 no barrier, 8 no chain fold (none of them changes an address).  Selected by DMDX_TN_ABLATE.
 // SK ("skinny rows"): 64 x 128 output tile, the four waves side by side (each 64 rows x 32
 //   columns = 2 x 1 MFMA blocks) -- for D with few rows (Z = X^T Y with l <= 64 columns of Y):
 //   half the MFMA work of a 128-row tile that would be half padding.
@@ -295,37 +301,30 @@ __global__ __launch_bounds__(NTH, 2) void gemm_tn_partial_kernel(TnParams p) {
 // The 8 pieces of the next chunk in one asm block: 2 SALU (M0) + 8 VMEM, no VALU.  A wave
 // whose SIMD partner streams MFMAs gets ~one instruction issued per MFMA slot (stamps:
 // ~64-95 cycles each), so every VALU address add in this phase cost a whole MFMA slot.
-#define DMDX_DMA_NEXT(ap, bp, la, lb)                                                              \
+#define DMDX_DMA_OP4(ptr, la, o0, o1, o2, o3)                                                      \
+  asm volatile("s_mov_b32 m0, %[la_]\n\ts_nop 0\n\t"                                               \
+               "global_load_lds_dwordx4 %[a0], %[ap_]\n\t"                                         \
+               "global_load_lds_dwordx4 %[a1], %[ap_] offset:1024\n\t"                             \
+               "global_load_lds_dwordx4 %[a2], %[ap_] offset:2048\n\t"                             \
+               "global_load_lds_dwordx4 %[a3], %[ap_] offset:3072"                                 \
+               :: [la_] "s"(la), [ap_] "s"(ptr), [a0] "v"(o0), [a1] "v"(o1), [a2] "v"(o2), [a3] "v"(o3) \
+               : "memory")
+#define DMDX_DMA_OP2(ptr, la, o0, o1)                                                              \
+  asm volatile("s_mov_b32 m0, %[la_]\n\ts_nop 0\n\t"                                               \
+               "global_load_lds_dwordx4 %[a0], %[ap_]\n\t"                                         \
+               "global_load_lds_dwordx4 %[a1], %[ap_] offset:1024"                                 \
+               :: [la_] "s"(la), [ap_] "s"(ptr), [a0] "v"(o0), [a1] "v"(o1)                         \
+               : "memory")
+#define DMDX_DMA_A(ap, la)                                                                         \
   do {                                                                                             \
-    if constexpr (NPA == 4)                                                                        \
-      asm volatile("s_mov_b32 m0, %[la_]\n\ts_nop 0\n\t"                                           \
-                   "global_load_lds_dwordx4 %[a0], %[ap_]\n\t"                                     \
-                   "global_load_lds_dwordx4 %[a1], %[ap_] offset:1024\n\t"                         \
-                   "global_load_lds_dwordx4 %[a2], %[ap_] offset:2048\n\t"                         \
-                   "global_load_lds_dwordx4 %[a3], %[ap_] offset:3072\n\t"                         \
-                   "s_mov_b32 m0, %[lb_]\n\ts_nop 0\n\t"                                           \
-                   "global_load_lds_dwordx4 %[b0], %[bp_]\n\t"                                     \
-                   "global_load_lds_dwordx4 %[b1], %[bp_] offset:1024\n\t"                         \
-                   "global_load_lds_dwordx4 %[b2], %[bp_] offset:2048\n\t"                         \
-                   "global_load_lds_dwordx4 %[b3], %[bp_] offset:3072"                             \
-                   :: [la_] "s"(la), [lb_] "s"(lb), [ap_] "s"(ap), [bp_] "s"(bp),                   \
-                      [a0] "v"(aoffb[0]), [a1] "v"(aoffb[1]), [a2] "v"(aoffb[NPA - 2]),            \
-                      [a3] "v"(aoffb[NPA - 1]), [b0] "v"(boffb[0]), [b1] "v"(boffb[1]),            \
-                      [b2] "v"(boffb[2]), [b3] "v"(boffb[3])                                       \
-                   : "memory");                                                                    \
-    else                                                                                           \
-      asm volatile("s_mov_b32 m0, %[la_]\n\ts_nop 0\n\t"                                           \
-                   "global_load_lds_dwordx4 %[a0], %[ap_]\n\t"                                     \
-                   "global_load_lds_dwordx4 %[a1], %[ap_] offset:1024\n\t"                         \
-                   "s_mov_b32 m0, %[lb_]\n\ts_nop 0\n\t"                                           \
-                   "global_load_lds_dwordx4 %[b0], %[bp_]\n\t"                                     \
-                   "global_load_lds_dwordx4 %[b1], %[bp_] offset:1024\n\t"                         \
-                   "global_load_lds_dwordx4 %[b2], %[bp_] offset:2048\n\t"                         \
-                   "global_load_lds_dwordx4 %[b3], %[bp_] offset:3072"                             \
-                   :: [la_] "s"(la), [lb_] "s"(lb), [ap_] "s"(ap), [bp_] "s"(bp),                   \
-                      [a0] "v"(aoffb[0]), [a1] "v"(aoffb[1]), [b0] "v"(boffb[0]),                  \
-                      [b1] "v"(boffb[1]), [b2] "v"(boffb[2]), [b3] "v"(boffb[3])                   \
-                   : "memory");                                                                    \
+    if constexpr (NPA == 4) DMDX_DMA_OP4(ap, la, aoffb[0], aoffb[1], aoffb[NPA - 2], aoffb[NPA - 1]); \
+    else DMDX_DMA_OP2(ap, la, aoffb[0], aoffb[1]);                                                 \
+  } while (0)
+#define DMDX_DMA_B(bp, lb) DMDX_DMA_OP4(bp, lb, boffb[0], boffb[1], boffb[2], boffb[3])
+#define DMDX_DMA_NEXT(ap, bp, la, lb) \
+  do {                                \
+    DMDX_DMA_A(ap, la);               \
+    DMDX_DMA_B(bp, lb);               \
   } while (0)
   auto stage_dma = [&](int chunk, int st) {
     const int64_t k0 = (int64_t)chunk * BK;
@@ -361,13 +360,21 @@ __global__ __launch_bounds__(NTH, 2) void gemm_tn_partial_kernel(TnParams p) {
     if constexpr (NI == 2) FB[NI - 1] = *reinterpret_cast<const f32x4*>(bs_ + 32 * BK); \
   } while (0)
 
+  // ---- chunk pipeline.  Both stages are filled up front; chunk c computes k-steps 0..2 from
+  // stage `cur`, then the barrier (all waves are done reading `cur`: the k-step-3 fragments
+  // are already in registers; chunk c+1 has landed in the other stage), then the refill of
+  // `cur` with chunk c+2 and the first fragment reads of chunk c+1 are issued and k-step 3
+  // runs behind them -- the wave leaves the barrier with 16 MFMAs to issue while its LDS
+  // reads and LDS-DMA pieces are in flight, and every LDS-DMA has a whole chunk to land.
+  // Measured on cfg2 blocks: barrier after k-step 3 + refill before it 85.6 %, this order
+  // 87.4 %; pieces issued between the MFMAs of k-step 3 81 %; s_setprio 3 around the
+  // refill 68 %.
   stage(c_begin, 0);
+  if (nchunks > 1 && !(ABL & 1)) stage(c_begin + 1, 1);
   if (DMA) __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0), see the main loop
   __syncthreads();
   DMDX_READ_FRAGS(fa0, fb0, 0, 0);
 
-  // DMA pair i = pieces i of A and B of the next chunk.  (Issuing the pairs between the
-  // MFMAs of the k-steps instead of up front measured 1-2 % slower.)
 #define DMDX_MFMA4(FA, FB, j)                                                                   \
   do {                                                                                          \
     _Pragma("unroll") for (int mi_ = 0; mi_ < 2; ++mi_)                                         \
@@ -385,21 +392,15 @@ __global__ __launch_bounds__(NTH, 2) void gemm_tn_partial_kernel(TnParams p) {
   } while (0)
 
 #ifdef DMDX_STAMPS
+  unsigned long long rt0, rt1, ct0;
+  asm volatile("s_memrealtime %0\n\ts_memtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt0), "=s"(ct0)::"memory");
   unsigned long long st0 = 0, st1 = 0, st2 = 0, st2b = 0, st3 = 0, st4 = 0, sa0 = 0, sa1 = 0, sa2 = 0, sa3 = 0, sa5 = 0;
 #endif
   int cur = 0;
   for (int c = 0; c < nchunks; ++c) {
     DMDX_STAMP(st0);
     const bool has_next = (c + 1 < nchunks) && !(ABL & 1);
-    const bool dma_next = DMA && has_next && (c_begin + c + 1 != tail_chunk);
-    const int64_t knext = (int64_t)(c_begin + c + 1) * BK;
-    float* dma_as = lds + (cur ^ 1) * STG + ((TM / 4) * wave) * BK;
-    float* dma_bs = lds + (cur ^ 1) * STG + OPA + (32 * wave) * BK;
     const int phase = c & (FOLD / 4 - 1), fq = (c / (FOLD / 4)) & 3;
-    if (dma_next) {  // all pieces of one operand share one M0 value (see stage_dma)
-      DMDX_DMA_NEXT(Adma + 4 * knext, Bdma + 4 * knext,
-                    (unsigned)(uintptr_t)DMDX_LDS_PTR(dma_as), (unsigned)(uintptr_t)DMDX_LDS_PTR(dma_bs));
-    }
     DMDX_STAMP(st1);
     DMDX_READ_FRAGS(fa1, fb1, cur, 1);
     __builtin_amdgcn_sched_group_barrier(0x100, 2 + NI, 0);   // ds_reads of the next fragments
@@ -410,16 +411,17 @@ __global__ __launch_bounds__(NTH, 2) void gemm_tn_partial_kernel(TnParams p) {
     DMDX_READ_FRAGS(fa1, fb1, cur, 3);
     __builtin_amdgcn_sched_group_barrier(0x100, 2 + NI, 0);
     DMDX_KSTEP(fa0, fb0, 2);
-    DMDX_KSTEP(fa1, fb1, 3);
     DMDX_STAMP(st2);
-    if (has_next && !dma_next) stage_regs(c_begin + c + 1, cur ^ 1, c_begin + c + 1 == tail_chunk);
 
     if (DMA) __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): the asm LDS-DMA pieces are invisible to the compiler's counters
     DMDX_STAMP(st2b);
-    if (!(ABL & 2)) __syncthreads();  // waits for this wave's LDS-DMA (vmcnt) and for every wave's reads of `cur`
+    if (!(ABL & 2)) __syncthreads();
+    if (c + 2 < nchunks && !(ABL & 1)) stage(c_begin + c + 2, cur);
     cur ^= 1;
     DMDX_STAMP(st3);
     if (has_next) DMDX_READ_FRAGS(fa0, fb0, cur, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 2 + NI, 0);
+    DMDX_KSTEP(fa1, fb1, 3);
     if (!(ABL & 8) && phase == FOLD / 4 - 1) {
       switch (fq) {
         case 0: DMDX_FOLD(0, 0); break;
@@ -438,6 +440,9 @@ __global__ __launch_bounds__(NTH, 2) void gemm_tn_partial_kernel(TnParams p) {
     atomicAdd(&dmdx_stamp[0], sa0); atomicAdd(&dmdx_stamp[1], sa1);
     atomicAdd(&dmdx_stamp[2], sa2); atomicAdd(&dmdx_stamp[3], sa3);
     atomicAdd(&dmdx_stamp[5], sa5);
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt1)::"memory");
+    atomicAdd(&dmdx_stamp[6], st4 - ct0);   // core-clock cycles of this wave's chunk loop
+    atomicAdd(&dmdx_stamp[7], rt1 - rt0);   // the same interval in 100 MHz reference ticks
     atomicAdd(&dmdx_stamp[4], (unsigned long long)nchunks);
   }
 #endif
@@ -446,6 +451,10 @@ __global__ __launch_bounds__(NTH, 2) void gemm_tn_partial_kernel(TnParams p) {
 #undef DMDX_MFMA4
 #undef DMDX_KSTEP
 #undef DMDX_DMA_NEXT
+#undef DMDX_DMA_A
+#undef DMDX_DMA_B
+#undef DMDX_DMA_OP4
+#undef DMDX_DMA_OP2
 #undef DMDX_FOLD
 #undef DMDX_COMMIT_ALL
 #undef DMDX_COMMIT

@@ -283,3 +283,52 @@ def test_blocked_svd_equals_unblocked(monkeypatch):
     rr = dsvd.svd_randomized(Xt, 12, delay=2, random_state=0)
     assert torch.allclose(rr.s, brand.s, rtol=1e-5)
     assert torch.allclose(rr.Ut, brand.Ut, atol=1e-4)
+
+
+# ---------------------------------------------------------------- BASELINE cfg2 at full size
+def test_cfg2_full_size_svd_properties(K):
+    """cfg2 (1 038 240 x 8760 fp32, rank 50) is far beyond what the oracle can factor, so the
+    full-size run is checked through properties that do not depend on the size:
+      * the planted spectrum: X = A diag(sigma) B^T + noise with Gaussian A, B has singular values
+        ~ sigma_i sqrt(m n) (tolerance 5 %: B^T B / n = I + O(n^-1/2) for the Gaussian factor),
+      * s non-increasing, V V^T = I (fp64, 1e-10), U^T U = I (fp64 torch products, 2e-5),
+      * the defining relation X^T u_j = s_j v_j, evaluated in fp64 by torch on one row block
+        at a time (1e-6 s_1 -- fp32 storage of X and U -- and 1e-4 s_j),
+      * Gram invariants of one full-size row block: symmetry (exact), trace(G) = ||X||_F^2 (1e-6).
+    """
+    import bench
+    from dmd_era5_amd import svd as dsvd
+
+    free, _ = torch.cuda.mem_get_info()
+    if free < 60 * 2**30:
+        pytest.skip("needs ~45 GB of HBM")
+    m, n, r, _ = bench.WORKLOADS["cfg2"]
+    blocks = bench.make_snapshot_blocks(m, n, 1234, torch.device("cuda"))
+    for B in blocks:
+        K.row_center_scale_(B, False)
+    res = dsvd.svd_snapshots(blocks, r, kern=K)
+    s, Vh, Ut = res.s, res.Vh, res.Ut
+    assert Ut.shape == (r, m) and Vh.shape == (r, n) and s.shape == (r,)
+    assert bool((s[:-1] >= s[1:]).all())
+    sig = 100.0 * 0.9 ** np.arange(r)
+    planted = sig * np.sqrt(float(m) * n)
+    assert np.all(np.abs(s.cpu().numpy() / planted - 1.0) < 0.05)
+    eye = torch.eye(r, dtype=torch.float64, device="cuda")
+    assert float((Vh @ Vh.T - eye).abs().max()) < 1e-10
+    UtU = torch.zeros((r, r), dtype=torch.float64, device="cuda")
+    XtU = torch.zeros((n, r), dtype=torch.float64, device="cuda")
+    r0 = 0
+    for B in blocks:                                   # B: (n, mb) = block of X^T
+        Ub = Ut[:, r0:r0 + B.shape[1]].double()        # (r, mb)
+        UtU += Ub @ Ub.T
+        for j0 in range(0, n, 2190):                   # fp64 copies of the block in column slabs
+            XtU[j0:j0 + 2190] += B[j0:j0 + 2190].double() @ Ub.T
+        r0 += B.shape[1]
+    assert float((UtU - eye).abs().max()) < 2e-5
+    err = (XtU - (Vh.T * s)).norm(dim=0)
+    assert float((err / s[0]).max()) < 1e-6        # fp32 data: errors scale with eps32 * s_1
+    assert float((err / s).max()) < 1e-4           # ... so s_50 = 0.006 s_1 keeps 4 digits
+    G = K.syrk(blocks[0])
+    assert torch.equal(G, G.T)
+    fro = sum(float((blocks[0][j0:j0 + 1024].double() ** 2).sum()) for j0 in range(0, n, 1024))
+    assert abs(float(torch.trace(G)) / fro - 1.0) < 1e-6

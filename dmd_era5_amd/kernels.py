@@ -69,10 +69,12 @@ class HipKernels:
         return rc
 
     def _workspace(self, device: torch.device, nbytes: int) -> torch.Tensor:
+        # one scratch buffer per (device, stream): launches on different streams may overlap
         idx = device.index if device.index is not None else torch.cuda.current_device()
-        ws = self._ws.get(idx)
+        key = (idx, torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
+        ws = self._ws.get(key)
         if ws is None or ws.numel() < nbytes:
-            self._ws[idx] = ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=device)
+            self._ws[key] = ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=device)
         return ws
 
     # -- K1 -----------------------------------------------------------------

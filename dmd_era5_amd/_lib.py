@@ -34,6 +34,8 @@ SIGNATURES = {
     "dmdx_row_center_scale_f32": (C.c_int, [_p, _i64, _i64, _i64, _p, _p, C.c_int, _p]),
     "dmdx_delay_shift_sum_f64": (C.c_int, [_p, _i64, _i64, C.c_int, _p, _i64, _p, _i64, _p]),
     "dmdx_scale_columns_f32": (C.c_int, [_p, _i64, _i64, _i64, _p, _p]),
+    "dmdx_eigh_small_max_n": (C.c_int, []),
+    "dmdx_eigh_small_f64": (C.c_int, [_p, _i64, _i64, _p, _p, _i64, _p, _p]),
 }
 
 _lib = None

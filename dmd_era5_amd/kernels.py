@@ -184,6 +184,28 @@ class HipKernels:
         return Yt
 
 
+    # -- K7 -----------------------------------------------------------------
+    @property
+    def eigh_small_max_n(self) -> int:
+        return int(self._lib.dmdx_eigh_small_max_n())
+
+    def eigh_small(self, T: torch.Tensor):
+        """Eigenpairs of a small symmetric fp64 device matrix (n <= eigh_small_max_n), one
+        launch: -> (w (n,) descending, V (n, n) with the eigenvectors in its columns)."""
+        if T.dim() != 2 or T.shape[0] != T.shape[1] or T.dtype != torch.float64 or not T.is_cuda:
+            raise _lib.DmdxError("eigh_small: T must be a square fp64 device matrix")
+        if T.stride(1) != 1:
+            T = T.contiguous()
+        n = T.shape[0]
+        w = torch.empty(n, dtype=torch.float64, device=T.device)
+        V = torch.empty((n, n), dtype=torch.float64, device=T.device)
+        rc = self._timed("eigh_small", (n,), lambda: self._lib.dmdx_eigh_small_f64(
+            _ptr(T), n, T.stride(0), _ptr(w), _ptr(V), n, None, self._stream()
+        ))
+        _lib.check(rc, "dmdx_eigh_small_f64")
+        return w, V
+
+
 _default: HipKernels | None = None
 
 

@@ -147,8 +147,19 @@ def _orth(Y: torch.Tensor) -> torch.Tensor:
     return Q.contiguous()
 
 
+def _eigh_desc(T: torch.Tensor, kern=None):
+    """Eigenpairs of a small symmetric fp64 matrix, eigenvalues descending, eigenvectors in
+    columns.  Up to the provider's ``eigh_small_max_n`` (96) this is ONE launch of the Jacobi
+    kernel K7; rocSOLVER's syevd (torch.linalg.eigh) is launch-rate bound at these sizes."""
+    n = T.shape[0]
+    if kern is not None and n <= getattr(kern, "eigh_small_max_n", 0):
+        return kern.eigh_small(T)
+    th, Z = torch.linalg.eigh(T)
+    return torch.flip(th, dims=(0,)), torch.flip(Z, dims=(1,))
+
+
 def top_eigh(G: torch.Tensor, l: int, method: str = "auto", tol: float = 1e-11,
-             max_outer: int = 40, info: dict | None = None):
+             max_outer: int = 40, info: dict | None = None, kern=None):
     """Largest ``l`` eigenpairs of the symmetric PSD fp64 matrix ``G`` (n x n),
     eigenvalues descending.
 
@@ -173,30 +184,57 @@ def top_eigh(G: torch.Tensor, l: int, method: str = "auto", tol: float = 1e-11,
     gen = torch.Generator(device=G.device).manual_seed(1234)  # (a host draw + upload costs 7 ms)
     Q = torch.randn((n, b), dtype=torch.float64, generator=gen, device=G.device)
     Q = _orth(G @ Q)
-    lam = V = None
-    for it in range(max_outer):
-        Y1 = _orth(G @ Q)
-        Y2 = G @ Y1
-        S = _orth(torch.cat([Q, Y1, Y2], dim=1))
-        GS = G @ S
+
+    def ritz(S, GS, want):
+        """Rayleigh-Ritz of G in span(S) (S orthonormal, GS = G S): Ritz values (descending),
+        Ritz vectors of the leading `want`, and the residual of the leading l relative to theta_1."""
         T = S.T @ GS
         T = 0.5 * (T + T.T)
-        th, Z = torch.linalg.eigh(T)
-        th = torch.flip(th, dims=(0,))[:b]
-        Z = torch.flip(Z, dims=(1,))[:, :b]
-        Q = S @ Z
-        R = GS @ Z[:, :l] - Q[:, :l] * th[:l]
-        res = torch.linalg.vector_norm(R, dim=0).max() / th[0].abs().clamp_min(1e-300)
-        lam, V = th[:l], Q[:, :l]
-        if float(res) <= tol:
-            if info is not None:
-                info["eig_method"] = "krylov"
-                info["eig_outer_iters"] = it + 1
-                info["eig_residual"] = float(res)
-            return lam.contiguous(), V.contiguous()
+        th, Z = _eigh_desc(T, kern)
+        th, Z = th[:want], Z[:, :want]
+        Qn = S @ Z
+        R = GS @ Z[:, :l] - Qn[:, :l] * th[:l]
+        res = float(torch.linalg.vector_norm(R, dim=0).max() / th[0].abs().clamp_min(1e-300))
+        return th, Qn, res
+
+    def done(th, Qn, res, how, it):
+        if info is not None:
+            info["eig_method"] = how
+            info["eig_outer_iters"] = it
+            info["eig_residual"] = res
+        return th[:l].contiguous(), Qn[:, :l].contiguous()
+
+    # Fast path: three more block power steps, then ONE (b x b) Rayleigh-Ritz.  With a steep
+    # spectrum behind the block (lambda_{b+1} << lambda_l: every low-rank + noise matrix, cfg2,
+    # where the fp32 rounding of G leaves a floor of ~1e-9 lambda_1) this reaches the tolerance
+    # for a fraction of the cost of a Krylov sweep ((3b x 3b) eigensolve, (n x 3b)
+    # orthonormalisation); otherwise its Ritz vectors are the start of the Krylov sweeps.
+    for _ in range(2):
+        Q = _orth(G @ Q)
+    Y = G @ Q
+    th, Qn, res = ritz(Q, Y, b)
+    if res <= tol:
+        return done(th, Qn, res, "power", 1)
+    Q = Qn
+
+    def orth_against(Y, P):
+        """Orthonormal basis of the part of span(Y) outside span(P) (P orthonormal): block
+        Gram-Schmidt, projected twice, then CholeskyQR2 inside the block."""
+        for _ in range(2):
+            Y = Y - P @ (P.T @ Y)
+        return _orth(Y)
+
+    for it in range(max_outer):
+        Y1 = orth_against(G @ Q, Q)
+        P = torch.cat([Q, Y1], dim=1)
+        Y2 = orth_against(G @ Y1, P)
+        S = torch.cat([P, Y2], dim=1)
+        th, Q, res = ritz(S, G @ S, b)
+        if res <= tol:
+            return done(th, Q, res, "krylov", it + 1)
     if info is not None:
-        info["eig_krylov_failed_residual"] = float(res)
-    return top_eigh(G, l, method="full", info=info)
+        info["eig_krylov_failed_residual"] = res
+    return top_eigh(G, l, method="full", info=info, kern=kern)
 
 
 # ---------------------------------------------------------------------------
@@ -326,7 +364,7 @@ def svd_snapshots(Xt, n_components: int, delay: int = 1, oversample: int | None 
     k = min(n_components, nd, Mg)  # np.linalg.svd(full_matrices=False)[:k]
     p = oversample if oversample is not None else max(8, k // 4)
     l = min(nd, k + p) if refine else k
-    lam, V = top_eigh(G, l, method=eig_method, info=info)
+    lam, V = top_eigh(G, l, method=eig_method, info=info, kern=kern)
     comm.broadcast_(lam, V)
     lam1 = lam[0].clamp_min(1e-300)
     good = lam > lam1 * 1e-14
@@ -345,9 +383,9 @@ def svd_snapshots(Xt, n_components: int, delay: int = 1, oversample: int | None 
         Mm = _gram_blocks(Up, kern, comm)                         # (l, l) fp64
         T = s0[:, None] * Mm * s0[None, :]
         T = 0.5 * (T + T.T)
-        mu, Z = torch.linalg.eigh(T)
-        mu = torch.flip(mu, dims=(0,))[:k].contiguous()
-        Z = torch.flip(Z, dims=(1,))[:, :k].contiguous()
+        mu, Z = _eigh_desc(T, kern)
+        mu = mu[:k].contiguous()
+        Z = Z[:, :k].contiguous()
         comm.broadcast_(mu, Z)
         s = torch.sqrt(mu.clamp_min(0.0))
         ok = s > s0[0] * 1e-7

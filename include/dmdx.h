@@ -100,6 +100,16 @@ int dmdx_delay_shift_sum_f64(const double* G, int64_t n, int64_t ldg, int d,
 int dmdx_scale_columns_f32(float* Y, int64_t m, int64_t l, int64_t ldy,
                            const float* alpha, void* stream);
 
+/* ---- K7: eigenpairs of a small symmetric fp64 matrix, one launch -------------
+ * A (n x n, lda, either storage order: only (A + A^T)/2 is used), n <= dmdx_eigh_small_max_n()
+ * (96).  w[0..n) eigenvalues in DESCENDING order, V (n x n, row-major, ldv): column j is the
+ * unit eigenvector of w[j].  sweeps: nullable device int, number of Jacobi sweeps used.
+ * Replaces the LAPACK syevd calls on the projected matrices of the method of snapshots (the
+ * part of np.linalg.svd, era5_svd.py:251, that is left once X is reduced to its Gram matrix). */
+int dmdx_eigh_small_max_n(void);
+int dmdx_eigh_small_f64(const double* A, int64_t n, int64_t lda, double* w, double* V,
+                        int64_t ldv, int* sweeps, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

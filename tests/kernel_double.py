@@ -48,3 +48,9 @@ class CpuKernelDouble:
     def scale_columns_(self, Yt, alpha):
         Yt *= alpha[:, None]
         return Yt
+
+    eigh_small_max_n = 96
+
+    def eigh_small(self, T):
+        w, V = torch.linalg.eigh(0.5 * (T + T.T))
+        return torch.flip(w, dims=(0,)), torch.flip(V, dims=(1,))

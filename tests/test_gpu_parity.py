@@ -332,3 +332,37 @@ def test_cfg2_full_size_svd_properties(K):
     assert torch.equal(G, G.T)
     fro = sum(float((blocks[0][j0:j0 + 1024].double() ** 2).sum()) for j0 in range(0, n, 1024))
     assert abs(float(torch.trace(G)) / fro - 1.0) < 1e-6
+
+
+# ---------------------------------------------------------------- K7 small eigensolver
+@pytest.mark.parametrize("n", [1, 2, 3, 17, 62, 77, 96])
+def test_eigh_small_matches_lapack(K, n):
+    """One-launch Jacobi vs numpy's LAPACK on a graded matrix (eigenvalues over 12 decades):
+    eigenvalues to 1e-13 of the largest (the stored A determines the small ones no better),
+    V orthonormal to 1e-13, A V = V diag(w) to 1e-13 ||A||."""
+    rs = np.random.RandomState(n)
+    Qm, _ = np.linalg.qr(rs.standard_normal((n, n)))
+    lam = 10.0 ** np.linspace(6, -6, n)
+    A = (Qm * lam) @ Qm.T
+    A = 0.5 * (A + A.T)
+    w, V = K.eigh_small(_dev(A))
+    w, V = w.cpu().numpy(), V.cpu().numpy()
+    ref = np.linalg.eigvalsh(A)[::-1]
+    assert np.all(np.diff(w) <= 0)
+    assert np.abs(w - ref).max() <= 1e-13 * ref[0]
+    assert np.abs(V.T @ V - np.eye(n)).max() <= 1e-13
+    assert np.abs(A @ V - V * w).max() <= 1e-13 * ref[0]
+
+
+def test_eigh_small_indefinite_repeated_and_limits(K):
+    A = np.diag([3.0, 3.0, -1.0, 0.0, 3.0])
+    A[0, 1] = A[1, 0] = 1e-3
+    w, V = K.eigh_small(_dev(A))
+    ref = np.linalg.eigvalsh(A)[::-1]
+    assert np.abs(w.cpu().numpy() - ref).max() < 1e-14
+    assert np.abs(A @ V.cpu().numpy() - V.cpu().numpy() * w.cpu().numpy()).max() < 1e-14
+    assert K.eigh_small_max_n == 96
+    from dmd_era5_amd._lib import DmdxError
+
+    with pytest.raises(DmdxError):
+        K.eigh_small(torch.zeros((97, 97), dtype=torch.float64, device="cuda"))

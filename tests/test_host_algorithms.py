@@ -39,11 +39,26 @@ def test_top_eigh_krylov_equals_full():
     A = rs.standard_normal((3000, 400)) * (0.97 ** np.arange(400))
     G = torch.from_numpy(A.T @ A)
     info = {}
-    lam_k, V_k = dsvd.top_eigh(G, 20, method="krylov", info=info)
+    lam_k, V_k = dsvd.top_eigh(G, 20, method="krylov", info=info, kern=K)
     lam_f, V_f = dsvd.top_eigh(G, 20, method="full")
     assert info["eig_method"] == "krylov"
     assert torch.allclose(lam_k, lam_f, rtol=1e-10)
     assert (V_k * V_f).sum(dim=0).abs().min() > 1 - 1e-8
+
+
+def test_top_eigh_power_fast_path_on_lowrank_plus_noise():
+    """A steep drop behind the block (cfg2's spectrum shape) is finished by the (b x b) power /
+    Rayleigh-Ritz steps; a slowly decaying one (the test above) goes on to the Krylov sweeps."""
+    rs = np.random.RandomState(1)
+    A = rs.standard_normal((4000, 24)) * (100 * 0.9 ** np.arange(24))   # rank 24 < block width 28
+    X = A @ rs.standard_normal((24, 500)) + 1e-3 * rs.standard_normal((4000, 500))
+    G = torch.from_numpy(X.T @ X)
+    info = {}
+    lam_p, V_p = dsvd.top_eigh(G, 20, method="krylov", info=info, kern=K)
+    lam_f, V_f = dsvd.top_eigh(G, 20, method="full")
+    assert info["eig_method"] == "power" and info["eig_residual"] <= 1e-11
+    assert torch.allclose(lam_p, lam_f, rtol=1e-10)
+    assert (V_p * V_f).sum(dim=0).abs().min() > 1 - 1e-8
 
 
 def test_randomized_same_omega_as_sklearn():

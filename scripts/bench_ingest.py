@@ -37,3 +37,10 @@ t0 = time.perf_counter()
 res, _, _ = main(cfg, write_to_netcdf=True)
 print(f"main(): {time.perf_counter()-t0:.2f} s total; s head {res['s'].values[:3]}", flush=True)
 print("result file:", os.path.getsize(p["save_path"]) / 1e6, "MB")
+if os.environ.get("DMDX_PROFILE_MAIN"):
+    import cProfile, pstats
+    os.remove(p["save_path"])
+    pr = cProfile.Profile(); pr.enable()
+    main(cfg, write_to_netcdf=True)
+    pr.disable()
+    pstats.Stats(pr).sort_stats("cumulative").print_stats(35)

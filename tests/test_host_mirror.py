@@ -292,3 +292,55 @@ def test_hdf5_lazy_variables_and_time_slabs(tmp_path, monkeypatch):
     with hdf5_lite.Reader(path) as r:
         assert r.variables["temperature"][2] == ("time", "level", "latitude", "longitude")
         assert r.attrs("time")["units"].startswith("hours since")
+
+
+def test_hdf5_contiguous_datasets_are_read_by_parallel_preads(tmp_path, monkeypatch):
+    """Contiguous little-endian numeric datasets take the raw pread path (several threads);
+    it must return exactly what H5Dread returns, for whole reads and for time slabs."""
+    from dmd_era5_amd import hdf5_lite
+
+    if not hdf5_lite.available():
+        pytest.skip("libhdf5 not found")
+    rs = np.random.RandomState(0)
+    a = rs.standard_normal((40, 3, 90, 180)).astype(np.float32)       # 7.8 MB: a single piece
+    b = rs.standard_normal((70, 400, 400)).astype(np.float64)         # 89.6 MB: 11 pieces
+    path = str(tmp_path / "raw.nc")
+    with hdf5_lite.Writer(path) as w:
+        w.dataset("time", np.arange(40, dtype=np.int64), ("time",))
+        w.dataset("a", a, ("time", "level", "latitude", "longitude"))
+        w.dataset("b", b, ("t2", "y", "x"))
+    with hdf5_lite.Reader(path) as r:
+        assert {"a", "b", "time"} <= set(r.raw_offset)
+        assert np.array_equal(r.read("a"), a) and np.array_equal(r.read("b"), b)
+        assert np.array_equal(r.read_slab("b", 13, 57), b[13:57])
+        out = np.empty((5, 3, 90, 180), dtype=np.float32)
+        assert r.read_slab("a", 35, 40, out) is out and np.array_equal(out, a[35:])
+        monkeypatch.setattr(hdf5_lite, "RAW_READ_THREADS", 0)           # the H5Dread path
+        assert np.array_equal(r.read_slab("b", 13, 57), b[13:57])
+        with pytest.raises(ValueError):
+            r.read_slab("a", 0, 5, np.empty((5, 3, 90, 180), dtype=np.float64))
+
+
+def test_hdf5_label_coordinates_with_millions_of_strings(tmp_path):
+    """`original_variable (space)`-type coordinates: run-length factorised on write, converted by
+    the C helper on read (ASCII fast path, UTF-8 path, no-run fallback)."""
+    from dmd_era5_amd import hdf5_lite
+
+    if not hdf5_lite.available():
+        pytest.skip("libhdf5 not found")
+    runs = np.tile(np.repeat(np.array(["temperature", "u_component_of_wind", "v"]), 3000), 2)
+    utf8 = np.repeat(np.array(["température", "vent_zonal"]), 5000)
+    rs = np.random.RandomState(1)
+    norun = np.array(["n%d" % i for i in rs.randint(0, 50, 6000)])
+    path = str(tmp_path / "labels.nc")
+    with hdf5_lite.Writer(path) as w:
+        w.dataset("runs", runs, ("space",))
+        w.dataset("utf8", utf8, ("s2",))
+        w.dataset("norun", norun, ("s3",))
+        w.dataset("few", np.array(["a", "bb", ""]), ("s4",))
+    with hdf5_lite.Reader(path) as r:
+        for name, ref in (("runs", runs), ("utf8", utf8), ("norun", norun), ("few", np.array(["a", "bb", ""]))):
+            got = r.read(name)
+            assert got.shape == ref.shape and np.array_equal(got, ref), name
+    uq, inv = hdf5_lite._factorize(runs)
+    assert np.array_equal(uq[inv], runs) and len(uq) == 3

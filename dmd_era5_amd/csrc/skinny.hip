@@ -15,9 +15,13 @@
 // Workgroup = 4 waves = 512 rows; per wave 128 rows x 32*C columns of Y in
 // 4*C accumulators; K loop over n in chunks of 32 (16 MFMA k-steps), X loads
 // issued half a chunk (8 steps = 8 KiB per wave) ahead of their use.
+#include <type_traits>
+
 #include "dmdx_common.h"
 
 namespace {
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int KB = 32;          // k rows per W chunk
 constexpr int LDW = KB + 1;     // padded LDS row of the transposed W chunk
@@ -50,6 +54,13 @@ __global__ __launch_bounds__(256, (C <= 2 ? 2 : 1)) void skinny_kernel(
   const unsigned loff0 = (unsigned)crow;
   const unsigned loff = (unsigned)(crow + (int64_t)lh * ldx);
   const int64_t ku_max = (n - 1) & ~(int64_t)1;  // last even column index
+  // fast path (every column of the iteration in range): raw buffer loads -- a descriptor at
+  // the chunk's first column (SGPRs), the column as a scalar byte offset, the lane's rows as
+  // this 32-bit per-lane byte offset: no VALU and no 64-bit arithmetic per load
+  const unsigned loffb = 4u * loff;
+  const char* Xbytes = reinterpret_cast<const char*>(X);
+  const int64_t ldxb = 4 * ldx;
+  const bool fast_ok = 2 * KB * ldxb < (int64_t(1) << 31);  // scalar byte offsets stay 32-bit
 
   f32x16 acc[4][C];
 #pragma unroll
@@ -64,6 +75,13 @@ __global__ __launch_bounds__(256, (C <= 2 ? 2 : 1)) void skinny_kernel(
     const int64_t kc = ku < ku_max ? ku : ku_max;      // scalar clamp
     const float* q = X + kc * ldx;                       // uniform base
     const unsigned off = (kc + lh < n) ? loff : loff0;   // odd-n last column
+#if defined(DMDX_K2_ABL) && DMDX_K2_ABL == 2   /* timing only: no X loads */
+    if (ALIGNED) {
+      f32x4 v = {(float)off, (float)kc, 1.f, 2.f};
+      asm volatile("" : "+v"(v));
+      return v;
+    }
+#endif
     if (ALIGNED) {
       return *reinterpret_cast<const f32x4*>(q + off);
     } else {
@@ -120,19 +138,38 @@ __global__ __launch_bounds__(256, (C <= 2 ? 2 : 1)) void skinny_kernel(
   do {                                                                               \
     _Pragma("unroll") for (int cc = 0; cc < C; ++cc) dst[cc] = ws[32 * cc * LDW + 2 * (s_)]; \
   } while (0)
+#if defined(DMDX_K2_ABL) && DMDX_K2_ABL == 1   /* timing only: no MFMAs */
+#define DMDX_STEP(xreg, bv)                                                          \
+  do {                                                                               \
+    asm volatile("" ::"v"(xreg));                                                    \
+    _Pragma("unroll") for (int cc = 0; cc < C; ++cc) asm volatile("" ::"v"(bv[cc])); \
+  } while (0)
+#else
 #define DMDX_STEP(xreg, bv)                                                          \
   do {                                                                               \
     _Pragma("unroll") for (int e = 0; e < 4; ++e)                                    \
         _Pragma("unroll") for (int cc = 0; cc < C; ++cc) acc[e][cc] =                \
             __builtin_amdgcn_mfma_f32_32x32x2f32(xreg[e], bv[cc], acc[e][cc], 0, 0, 0); \
   } while (0)
+#endif
 
   int cur = 0;
-  for (int c = 0; c < nchunks; ++c) {
+  auto chunk = [&](int c, auto fast_tag) {
+    constexpr bool FAST = decltype(fast_tag)::value;
     const int64_t k0 = (int64_t)c * KB;
     const bool has_next = c + 1 < nchunks;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(Xbytes + k0 * ldxb), 0, -1, 0x00020000);  // 4 GiB window at column k0
+    auto ld = [&](int koff) -> f32x4 {   // columns k0 + koff, k0 + koff + 1
+      if constexpr (FAST) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)loffb, koff * (int)ldxb, 0);
+        return __builtin_bit_cast(f32x4, v);
+      } else {
+        return load_x(k0 + koff);
+      }
+    };
 #pragma unroll
-    for (int s = 0; s < 8; ++s) xb[s] = load_x(k0 + 16 + 2 * s);
+    for (int s = 0; s < 8; ++s) xb[s] = ld(16 + 2 * s);
     if (has_next) load_w(k0 + KB);
 
     const float* ws = &Ws[cur][l31 * LDW + lh];
@@ -151,7 +188,7 @@ __global__ __launch_bounds__(256, (C <= 2 ? 2 : 1)) void skinny_kernel(
     }
     if (has_next) {
 #pragma unroll
-      for (int s = 0; s < 8; ++s) xa[s] = load_x(k0 + KB + 2 * s);
+      for (int s = 0; s < 8; ++s) xa[s] = ld(KB + 2 * s);
     }
 #pragma unroll
     for (int s = 0; s < 8; s += 2) {
@@ -169,7 +206,11 @@ __global__ __launch_bounds__(256, (C <= 2 ? 2 : 1)) void skinny_kernel(
     if (has_next) store_w(cur ^ 1);
     __syncthreads();
     cur ^= 1;
-  }
+  };
+  int c = 0;
+  if (ALIGNED && fast_ok)  // every X column these iterations load (up to k0 + 2 KB - 1) is inside the matrix
+    for (; (int64_t)(c + 2) * KB <= n; ++c) chunk(c, std::true_type{});
+  for (; c < nchunks; ++c) chunk(c, std::false_type{});
 #undef DMDX_READ_B
 #undef DMDX_STEP
 

@@ -74,6 +74,46 @@ def make_snapshot_blocks(m: int, n: int, seed: int, device) -> list[torch.Tensor
     return blocks
 
 
+def calibrate(device) -> dict:
+    """What this GPU sustains, next to the nominal peaks the roofline is priced against
+    (SURVEY.md 8d): a register-only fp32 MFMA loop (dmdx_calib_mfma_f32, 2 waves per SIMD) and a
+    4 GiB device-to-device copy.  Reported only; `roofline.peak` stays the nominal 157.3."""
+    import ctypes as C
+
+    from dmd_era5_amd import _lib
+
+    lib = _lib.load()
+    cus = torch.cuda.get_device_properties(device).multi_processor_count
+    sink = torch.zeros(4, dtype=torch.float32, device=device)
+    flops = C.c_double(0.0)
+    stream = torch.cuda.current_stream(device).cuda_stream
+    best = 0.0
+    for it in range(4):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _lib.check(lib.dmdx_calib_mfma_f32(200000, cus, sink.data_ptr(), C.byref(flops), stream), "calib")
+        e1.record()
+        e1.synchronize()
+        if it:
+            best = max(best, flops.value / (e0.elapsed_time(e1) * 1e-3) / 1e12)
+    a = torch.empty(1 << 30, dtype=torch.float32, device=device)
+    b = torch.empty_like(a)
+    copy = 0.0
+    for it in range(4):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        b.copy_(a)
+        e1.record()
+        e1.synchronize()
+        if it:
+            copy = max(copy, 2.0 * a.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e12)
+    del a, b
+    return {"mfma_f32_tflops_measured": best, "mfma_f32_tflops_nominal": PEAK_FP32_MFMA_TFLOPS,
+            "hbm_copy_TBps_measured": copy, "hbm_TBps_nominal": 8.0, "compute_units": cus,
+            "how": "dmdx_calib_mfma_f32: 16 x 200000 v_mfma_f32_32x32x2_f32 per wave, 8 waves per CU; "
+                   "torch copy of 4 GiB (read + write bytes)"}
+
+
 def cpu_baseline(Xt: torch.Tensor, r: int) -> dict:
     """Oracle (np.linalg.svd + slice) on a bounded sample (leading rows of the first
     row block) of the same matrix."""
@@ -114,6 +154,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-calibrate", action="store_true",
+                    help="skip the ~0.3 s on-box micro-benchmarks (register-only fp32 MFMA loop, HBM copy)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -238,6 +280,8 @@ def main():
                      for k, v in (res.info if res is not None else {}).items()},
         "s_head": [float(x) for x in res.s[:3].cpu()] if res is not None else None,
     }
+    if rank == 0 and world == 1 and not args.no_calibrate:
+        out["calibration"] = calibrate(device)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(blocks[0], r)
     if rank == 0:

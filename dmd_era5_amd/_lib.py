@@ -36,6 +36,7 @@ SIGNATURES = {
     "dmdx_scale_columns_f32": (C.c_int, [_p, _i64, _i64, _i64, _p, _p]),
     "dmdx_eigh_small_max_n": (C.c_int, []),
     "dmdx_eigh_small_f64": (C.c_int, [_p, _i64, _i64, _p, _p, _i64, _p, _p]),
+    "dmdx_calib_mfma_f32": (C.c_int, [C.c_int, C.c_int, _p, C.POINTER(C.c_double), _p]),
 }
 
 _lib = None

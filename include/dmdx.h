@@ -110,6 +110,11 @@ int dmdx_eigh_small_max_n(void);
 int dmdx_eigh_small_f64(const double* A, int64_t n, int64_t lda, double* w, double* V,
                         int64_t ldv, int* sweeps, void* stream);
 
+/* ---- measurement aid (not on the path): register-only fp32 MFMA loop -----------
+ * 2 workgroups of 4 waves per CU, 16 * iters v_mfma_f32_32x32x2_f32 per wave; *flops_out
+ * (host pointer, nullable) receives the flops of the launch.  bench.py --calibrate times it. */
+int dmdx_calib_mfma_f32(int iters, int num_cus, float* sink, double* flops_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

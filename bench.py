@@ -222,13 +222,17 @@ def main():
     # per-kernel times from the HIP events recorded inside the timed region
     # (the Gram is one launch per row block: per-launch figures are sums over the blocks
     # of one step divided by the launches; flops likewise)
+    # (the Gram of the row blocks is ONE launch of the batched K1, dmdx_syrk_blocks_f32,
+    # followed by its reduce kernel on the same stream; both are inside the event pair)
     by_name: dict[str, list[float]] = {}
     for name, shape, e0, e1 in events:
-        key = name if not (name == "syrk" and shape[1] != n) else "syrk_small"
+        key = name
+        if name in ("syrk", "syrk_blocks"):
+            key = "syrk" if shape[1] == n else "syrk_small"
         by_name.setdefault(key, []).append(e0.elapsed_time(e1))
     nblk = len(blocks)
-    syrk_ms = float(np.mean(by_name["syrk"]))            # average launch (one row block)
-    flops = float(m) * n * (n + 1) / nblk                  # algorithmic flops of that launch
+    syrk_ms = float(np.mean(by_name["syrk"]))            # average Gram launch (all row blocks of X)
+    flops = float(m) * n * (n + 1)                         # algorithmic flops of that launch
     achieved = flops / (syrk_ms * 1e-3) / 1e12
 
     # HBM-side traffic of the Gram kernel: PMC numbers cannot be collected from inside this
@@ -264,7 +268,7 @@ def main():
         },
         "roofline": {
             "bound": "mfma",
-            "kernel": "gemm_tn_partial_kernel (K1 Gram, dmdx_syrk_f32)",
+            "kernel": "syrk_batch_kernel (K1 Gram of all row blocks in one launch, dmdx_syrk_blocks_f32)",
             "achieved": achieved,
             "peak": PEAK_FP32_MFMA_TFLOPS,
             "unit": "TFLOP/s",

@@ -25,6 +25,8 @@ SIGNATURES = {
     "dmdx_last_error": (C.c_char_p, []),
     "dmdx_syrk_workspace_bytes": (_sz, [_i64, _i64]),
     "dmdx_syrk_f32": (C.c_int, [_p, _i64, _i64, _i64, _p, _i64, _p, _i64, C.c_int, _p, _sz, _p]),
+    "dmdx_syrk_blocks_workspace_bytes": (_sz, [_p, C.c_int, _i64]),
+    "dmdx_syrk_blocks_f32": (C.c_int, [_p, _p, _p, C.c_int, _i64, _p, _i64, _p, _i64, C.c_int, _p, _sz, _p]),
     "dmdx_gemm_tn_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "dmdx_gemm_tn_f32": (
         C.c_int,

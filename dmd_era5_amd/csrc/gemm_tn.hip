@@ -53,7 +53,26 @@ struct TnParams {
   int nsplit;
   int chunks_total;
   int chunks_per_split;
-  double* P;        // [nsplit][ntiles][128*128]
+  double* P;        // [slab][ntiles][tile rows x 128] fp64 partial tiles; slab = K-split (of a block)
+};
+
+// A batch of SYRK row blocks in one launch: the Gram of a row-blocked snapshot matrix is the
+// sum over its blocks, and one launch per block leaves the GPU draining / refilling 8 times
+// (last partial round of units, reduce kernel, launch gap: ~1.5 % at cfg2).  Block j owns the
+// grid range [unit_begin[j], unit_begin[j+1]) (padded to multiples of 512 so that the XCD
+// patch mapping stays aligned; padding blocks exit at once) and the partial-tile slabs
+// [slab_begin[j], slab_begin[j+1]); the reduce kernel sums all slabs.
+constexpr int MAXB = 16;
+struct TnBatch {
+  const float* X[MAXB];
+  int64_t ldx[MAXB];
+  int64_t K[MAXB];
+  int chunks_total[MAXB];
+  int chunks_per_split[MAXB];
+  int nsplit[MAXB];
+  int unit_begin[MAXB + 1];
+  int slab_begin[MAXB + 1];
+  int nblocks;
 };
 
 // upper-triangle tile enumeration: super-rows of 4 tile rows, column-major
@@ -140,26 +159,17 @@ __device__ unsigned long long dmdx_stamp[8];
 // SK ("skinny rows"): 64 x 128 output tile, the four waves side by side (each 64 rows x 32
 //   columns = 2 x 1 MFMA blocks) -- for D with few rows (Z = X^T Y with l <= 64 columns of Y):
 //   half the MFMA work of a 128-row tile that would be half padding.
-template <bool DMA, int ABL = 0, bool SK = false>
-__global__ __launch_bounds__(NTH, 2) void gemm_tn_partial_kernel(TnParams p) {
+// One work unit: the K-range of `split` of the TM x 128 output tile at (row0, col0) (D rows <-
+// columns of A, D cols <- columns of B), written as fp64 into the partial tile Pt.
+// lds: 2 stages of (TM + 128) x 32 floats.
+template <bool DMA, int ABL, bool SK>
+__device__ __forceinline__ void tn_unit(const TnParams& p, const int split, const int row0, const int col0,
+                                        double* Pt, float* lds) {
   constexpr int TM = SK ? 64 : BT;   // tile rows    (columns of OpA)
   constexpr int NI = SK ? 1 : 2;     // 32-column MFMA blocks per wave
   constexpr int NPA = SK ? 2 : 4;    // 1 KiB pieces of the A panel per wave (or 16 B pieces per thread)
   constexpr int OPA = TM * BK, OPB = BT * BK, STG = OPA + OPB;  // floats per stage
-  __shared__ __attribute__((aligned(16))) float lds[2 * STG];
   // stage st: A panel at lds + st * STG, B panel at lds + st * STG + OPA
-
-  // ---- unit decode (XCD-aware) ----
-  const int total = gridDim.x;
-  int b = blockIdx.x;
-  int g = b >> 9;  // groups of 512 blocks: the 64 that land on one XCD (b % 8) take 64 consecutive units
-  int pos = ((g << 9) + 512 <= total) ? (g << 9) + (b & 7) * 64 + ((b & 511) >> 3) : b;
-  const int split = pos / p.ntiles;
-  const int tile = pos - split * p.ntiles;
-  int ta, tb;
-  decode_tile(p, tile, ta, tb);
-  const int row0 = ta * TM;  // D rows  <- columns of A
-  const int col0 = tb * BT;  // D cols  <- columns of B
 
   const int c_begin = split * p.chunks_per_split;
   int c_end = c_begin + p.chunks_per_split;
@@ -247,7 +257,6 @@ __global__ __launch_bounds__(NTH, 2) void gemm_tn_partial_kernel(TnParams p) {
     for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc2[mi][ni][r] = 0.f;
-  double* Pt = p.P + ((size_t)split * p.ntiles + tile) * (TM * BT);
   const int lane_off = (64 * wr + 4 * lh) * BT + (SK ? 32 : 64) * wc + l31;
 #define DMDX_BLOCK_OFF(mi, ni, r) ((32 * (mi) + ((r) & 3) + 8 * ((r) >> 2)) * BT + 32 * (ni))
 #define DMDX_FOLD(mi, ni)                                                         \
@@ -461,6 +470,50 @@ __global__ __launch_bounds__(NTH, 2) void gemm_tn_partial_kernel(TnParams p) {
 #undef DMDX_BLOCK_OFF
 }
 
+// XCD-aware unit order: groups of 512 consecutive blocks; the 64 blocks of a group that land on
+// one XCD (blockIdx % 8) take 64 consecutive units (an 8 x 8 patch of tiles).  `b` counts from
+// the start of a range whose first block index is a multiple of 8.
+__device__ __forceinline__ int xcd_unit(int b, int total) {
+  const int g = b >> 9;
+  return ((g << 9) + 512 <= total) ? (g << 9) + (b & 7) * 64 + ((b & 511) >> 3) : b;
+}
+
+template <bool DMA, int ABL = 0, bool SK = false>
+__global__ __launch_bounds__(NTH, 2) void gemm_tn_partial_kernel(TnParams p) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * ((SK ? 64 : BT) + BT) * BK];
+  const int pos = xcd_unit(blockIdx.x, gridDim.x);
+  const int split = pos / p.ntiles;
+  const int tile = pos - split * p.ntiles;
+  int ta, tb;
+  decode_tile(p, tile, ta, tb);
+  double* Pt = p.P + ((size_t)split * p.ntiles + tile) * ((SK ? 64 : BT) * BT);
+  tn_unit<DMA, ABL, SK>(p, split, ta * (SK ? 64 : BT), tb * BT, Pt, lds);
+}
+
+// SYRK over a batch of row blocks (TnBatch); p carries what the blocks share (n, tiles, P).
+template <bool DMA>
+__global__ __launch_bounds__(NTH, 2) void syrk_batch_kernel(TnParams p, TnBatch bt) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * (BT + BT) * BK];
+  const int b = blockIdx.x;
+  int j = 0;
+  while (j + 1 < bt.nblocks && b >= bt.unit_begin[j + 1]) ++j;
+  const int total = bt.nsplit[j] * p.ntiles;
+  const int local = b - bt.unit_begin[j];
+  if (local >= total) return;  // padding up to the next multiple of 512
+  const int pos = xcd_unit(local, total);
+  const int split = pos / p.ntiles;
+  const int tile = pos - split * p.ntiles;
+  int ta, tb;
+  decode_tri(tile, p.ntr, ta, tb);
+  p.A = p.B = bt.X[j];
+  p.lda = p.ldb = bt.ldx[j];
+  p.K = bt.K[j];
+  p.chunks_total = bt.chunks_total[j];
+  p.chunks_per_split = bt.chunks_per_split[j];
+  double* Pt = p.P + ((size_t)(bt.slab_begin[j] + split) * p.ntiles + tile) * (BT * BT);
+  tn_unit<DMA, 0, false>(p, split, ta * BT, tb * BT, Pt, lds);
+}
+
 // Sum the K-splits in fp64 and scatter the tile into D (row-major view:
 // D[i*ld + j], which is the column-major C of the C ABI with the operand
 // roles swapped by the host wrapper).  SYRK mode also writes the mirror.
@@ -614,6 +667,71 @@ int run_tn(const float* A, int64_t lda, const float* B, int64_t ldb, int64_t K, 
   return 0;
 }
 
+// ---- batched SYRK: G (+)= sum_j X_j^T X_j, blocks in groups of MAXB per launch
+size_t batch_group_ws(const int64_t* m, int nb, int64_t n) {
+  size_t slabs = 0;
+  Plan pl{};
+  for (int j = 0; j < nb; ++j) {
+    pl = make_plan(m[j], n, n, 1);
+    slabs += (size_t)pl.nsplit;
+  }
+  return slabs * (size_t)pl.ntiles * BT * BT * sizeof(double);
+}
+
+int run_syrk_batch(const float* const* X, const int64_t* m, const int64_t* ldx, int nblocks, int64_t n,
+                   double* G64, int64_t ldg, float* G32, int64_t ldg32, int accumulate, void* ws,
+                   size_t ws_bytes, hipStream_t stream) {
+  for (int j0 = 0; j0 < nblocks; j0 += MAXB) {
+    const int nb = nblocks - j0 < MAXB ? nblocks - j0 : MAXB;
+    const size_t need = batch_group_ws(m + j0, nb, n);
+    if (ws == nullptr || ws_bytes < need) {
+      dmdx_set_error("syrk_blocks: workspace %zu bytes < required %zu", ws_bytes, need);
+      return DMDX_E_WORKSPACE;
+    }
+    TnBatch bt{};
+    TnParams p{};
+    bool aligned = true;
+    int units = 0, slabs = 0;
+    Plan pl{};
+    for (int j = 0; j < nb; ++j) {
+      const int64_t ld = ldx[j0 + j];
+      if (ld >= (int64_t(1) << 24)) {
+        dmdx_set_error("syrk_blocks: ldx >= 2^24 not supported (use smaller row blocks)");
+        return DMDX_E_UNSUPPORTED;
+      }
+      pl = make_plan(m[j0 + j], n, n, 1);
+      bt.X[j] = X[j0 + j];
+      bt.ldx[j] = ld;
+      bt.K[j] = m[j0 + j];
+      bt.chunks_total[j] = pl.chunks_total;
+      bt.chunks_per_split[j] = pl.chunks_per_split;
+      bt.nsplit[j] = pl.nsplit;
+      bt.unit_begin[j] = units;
+      bt.slab_begin[j] = slabs;
+      const int u = pl.nsplit * pl.ntiles;
+      units += (j + 1 < nb) ? (u + 511) / 512 * 512 : u;
+      slabs += pl.nsplit;
+      aligned = aligned && (ld % 4 == 0) && dmdx_aligned16(X[j0 + j]) && ld < (int64_t(1) << 22);
+    }
+    bt.unit_begin[nb] = units;
+    bt.slab_begin[nb] = slabs;
+    bt.nblocks = nb;
+    p.nrow = p.ncol = (int)n;
+    p.ntr = pl.ntr; p.ntc = pl.ntc; p.ntiles = pl.ntiles; p.syrk = 1;
+    p.nsplit = slabs;
+    p.P = reinterpret_cast<double*>(ws);
+    if (aligned)
+      hipLaunchKernelGGL(syrk_batch_kernel<true>, dim3((unsigned)units), dim3(NTH), 0, stream, p, bt);
+    else
+      hipLaunchKernelGGL(syrk_batch_kernel<false>, dim3((unsigned)units), dim3(NTH), 0, stream, p, bt);
+    DMDX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3(pl.ntiles * 16), dim3(256), 0, stream, p.P, slabs, pl.ntiles,
+                       pl.ntr, pl.ntc, 1, (int)n, (int)n, G64, ldg, G32, ldg32, (accumulate || j0 > 0) ? 1 : 0, BT);
+    DMDX_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -644,6 +762,29 @@ int dmdx_syrk_f32(const float* X, int64_t m, int64_t n, int64_t ldx, double* G64
   DMDX_CHECK_ARG(ldx < (1ll << 24), "syrk: ldx >= 2^24 not supported (use row blocks)");
   return run_tn(X, ldx, X, ldx, m, n, n, 1, G64, ldg, G32, ldg32, accumulate, workspace, workspace_bytes,
                 (hipStream_t)stream);
+}
+
+size_t dmdx_syrk_blocks_workspace_bytes(const int64_t* m, int nblocks, int64_t n) {
+  if (!m || nblocks <= 0 || n <= 0) return 0;
+  size_t need = 0;
+  for (int j0 = 0; j0 < nblocks; j0 += MAXB) {
+    for (int j = j0; j < nblocks && j < j0 + MAXB; ++j)
+      if (m[j] < 1) return 0;
+    const size_t g = batch_group_ws(m + j0, nblocks - j0 < MAXB ? nblocks - j0 : MAXB, n);
+    if (g > need) need = g;
+  }
+  return need;
+}
+
+int dmdx_syrk_blocks_f32(const float* const* X, const int64_t* m, const int64_t* ldx, int nblocks, int64_t n,
+                         double* G64, int64_t ldg, float* G32, int64_t ldg32, int accumulate,
+                         void* workspace, size_t workspace_bytes, void* stream) {
+  DMDX_CHECK_ARG(X && m && ldx && G64 && nblocks >= 1, "syrk_blocks: null pointer or no blocks");
+  DMDX_CHECK_ARG(n >= 1 && n < (1 << 30) && ldg >= n && (!G32 || ldg32 >= n), "syrk_blocks: bad n / ldg");
+  for (int j = 0; j < nblocks; ++j)
+    DMDX_CHECK_ARG(X[j] && m[j] >= 1 && ldx[j] >= 1, "syrk_blocks: bad block %d", j);
+  return run_syrk_batch(X, m, ldx, nblocks, n, G64, ldg, G32, ldg32, accumulate, workspace, workspace_bytes,
+                        (hipStream_t)stream);
 }
 
 size_t dmdx_gemm_tn_workspace_bytes(int64_t K, int64_t na, int64_t nb) {

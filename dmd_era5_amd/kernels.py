@@ -100,6 +100,32 @@ class HipKernels:
         _lib.check(rc, "dmdx_syrk_f32")
         return (G64, G32) if want32 else G64
 
+    def syrk_blocks(self, blocks, out: torch.Tensor | None = None) -> torch.Tensor:
+        """G (+)= sum_j X_j^T X_j over a list of (n, m_j) fp32 row blocks, 16 blocks per launch."""
+        import ctypes as C
+
+        shapes = [_check_mat(B, torch.float32, "syrk_blocks X") for B in blocks]
+        n = shapes[0][1]
+        if any(s[1] != n for s in shapes):
+            raise _lib.DmdxError("syrk_blocks: the blocks must have the same number of columns")
+        dev = blocks[0].device
+        if out is not None:
+            if out.shape != (n, n) or out.dtype != torch.float64 or not out.is_contiguous():
+                raise _lib.DmdxError("syrk_blocks: out must be a contiguous (n, n) fp64 tensor")
+            G64 = out
+        else:
+            G64 = torch.empty((n, n), dtype=torch.float64, device=dev)
+        nb = len(blocks)
+        ptrs = (C.c_void_p * nb)(*[B.data_ptr() for B in blocks])
+        ms = (C.c_int64 * nb)(*[s[0] for s in shapes])
+        lds = (C.c_int64 * nb)(*[s[2] for s in shapes])
+        ws = self._workspace(dev, self._lib.dmdx_syrk_blocks_workspace_bytes(ms, nb, n))
+        rc = self._timed("syrk_blocks", (sum(s[0] for s in shapes), n, nb), lambda: self._lib.dmdx_syrk_blocks_f32(
+            ptrs, ms, lds, nb, n, _ptr(G64), n, None, 0, int(out is not None), _ptr(ws), ws.numel(), self._stream()
+        ))
+        _lib.check(rc, "dmdx_syrk_blocks_f32")
+        return G64
+
     # -- K3 -----------------------------------------------------------------
     def gemm_tn(self, At: torch.Tensor, Bt: torch.Tensor, want32: bool = False,
                 out: torch.Tensor | None = None):

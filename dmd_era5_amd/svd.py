@@ -275,9 +275,7 @@ def as_blocks(Xt) -> list[torch.Tensor]:
 
 
 def _gram_blocks(blocks, kern, comm: Comm) -> torch.Tensor:
-    G = None
-    for B in blocks:
-        G = kern.syrk(B) if G is None else kern.syrk(B, out=G)
+    G = kern.syrk_blocks(blocks) if len(blocks) > 1 else kern.syrk(blocks[0])
     return comm.allreduce_sum_(G)
 
 

@@ -61,6 +61,16 @@ int dmdx_syrk_f32(const float* X, int64_t m, int64_t n, int64_t ldx,
                   double* G64, int64_t ldg, float* G32, int64_t ldg32, int accumulate,
                   void* workspace, size_t workspace_bytes, void* stream);
 
+/* K1 over a list of row blocks in ONE launch per 16 blocks:  G (+)= sum_j X_j^T X_j.
+ * X, m, ldx: HOST arrays of nblocks device pointers / row counts / leading dimensions (block j is
+ * m[j] x n, column-major, ldx[j]); everything else as dmdx_syrk_f32.  Same arithmetic per block;
+ * the K-splits of all blocks are summed by one reduce kernel.  Replaces the per-block loop of
+ * launches (last partial round of units, reduce kernel and launch gap per block). */
+size_t dmdx_syrk_blocks_workspace_bytes(const int64_t* m, int nblocks, int64_t n);
+int dmdx_syrk_blocks_f32(const float* const* X, const int64_t* m, const int64_t* ldx, int nblocks,
+                         int64_t n, double* G64, int64_t ldg, float* G32, int64_t ldg32,
+                         int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- K3: C = A^T B, A: K x na, B: K x nb (both K-contiguous) ---------------
  * Z = X^T Y of the randomized range finder (extmath.py:351, `A.T @ Q`) and
  * B = Q^T X (extmath.py:577).  C64: na x nb fp64 (ldc); C32 nullable.  */

@@ -8,12 +8,15 @@ ap.add_argument("--m", type=int, default=259560)
 ap.add_argument("--n", type=int, default=8760)
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--blocks", type=int, default=1)
+ap.add_argument("--batched", action="store_true", help="one launch for all blocks (dmdx_syrk_blocks_f32)")
 a = ap.parse_args()
 K = default_kernels()
 g = torch.Generator(device="cuda").manual_seed(1)
 mb = a.m // a.blocks
 Xb = [torch.randn((a.n, mb), generator=g, device="cuda", dtype=torch.float32) for _ in range(a.blocks)]
 def gram():
+    if a.batched:
+        return K.syrk_blocks(Xb)
     G = K.syrk(Xb[0])
     for B in Xb[1:]: K.syrk(B, out=G)
     return G
@@ -24,4 +27,4 @@ for _ in range(a.reps):
     G = gram(); torch.cuda.synchronize()
     ms.append(sum(e0.elapsed_time(e1) for _, _, e0, e1 in K.events))
 fl = a.m * a.n * (a.n + 1)
-print(f"syrk m={a.m} n={a.n} blocks={a.blocks}: {min(ms):.2f} ms best, {sum(ms)/len(ms):.2f} avg -> {fl/min(ms)/1e9:.1f} TFLOP/s best ({fl/min(ms)/1e9/157.3*100:.1f}% of 157.3)", flush=True)
+print(("batched " if a.batched else "") + f"syrk m={a.m} n={a.n} blocks={a.blocks}: {min(ms):.2f} ms best, {sum(ms)/len(ms):.2f} avg -> {fl/min(ms)/1e9:.1f} TFLOP/s best ({fl/min(ms)/1e9/157.3*100:.1f}% of 157.3)", flush=True)

@@ -6,8 +6,8 @@ usage: summarize_profiles.py <raw dir> <out dir> <tag>
 """
 import csv, glob, json, os, shutil, sys
 
-GRAM = "gemm_tn_partial_kernel<true, 0"      # the cfg2 Gram launches (128 x 128 tiles, LDS-DMA)
-M_BLOCK, N = 129780, 8760                     # one cfg2 row block
+GRAM = "syrk_batch_kernel<true>"              # the cfg2 Gram launch (all 8 row blocks, LDS-DMA)
+M_BLOCK, N = 1038240, 8760                    # rows of X covered by one launch
 
 
 def find(d, suffix):

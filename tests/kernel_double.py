@@ -20,6 +20,12 @@ class CpuKernelDouble:
             G = out
         return (G, G.float()) if want32 else G
 
+    def syrk_blocks(self, blocks, out=None):
+        G = out
+        for B in blocks:
+            G = self.syrk(B) if G is None else self.syrk(B, out=G)
+        return G
+
     def gemm_tn(self, At, Bt, want32=False, out=None):
         C = Bt.to(torch.float64) @ At.to(torch.float64).T
         if out is not None:

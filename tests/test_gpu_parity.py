@@ -366,3 +366,28 @@ def test_eigh_small_indefinite_repeated_and_limits(K):
 
     with pytest.raises(DmdxError):
         K.eigh_small(torch.zeros((97, 97), dtype=torch.float64, device="cuda"))
+
+
+# ---------------------------------------------------------------- K1 over a list of row blocks
+@pytest.mark.parametrize("sizes,n", [([5000, 3000, 4097], 260), ([700] * 19, 70), ([1024, 7], 129),
+                                     ([30001, 29999], 384)])
+def test_syrk_blocks_equals_sum_of_block_grams(K, sizes, n):
+    """dmdx_syrk_blocks_f32 (one launch per 16 blocks) against the fp64 Gram of the stacked rows,
+    same bound as the single-block test; ragged block sizes, > 16 blocks, unaligned blocks,
+    and accumulation into an existing G."""
+    rs = np.random.RandomState(sum(sizes) + n)
+    mats = [_rand(rs, m, n) for m in sizes]
+    blocks = [_dev(a.T) for a in mats]
+    G = K.syrk_blocks(blocks).cpu().numpy()
+    X = np.concatenate(mats).astype(np.float64)
+    ref = X.T @ X
+    absref = np.abs(X).T @ np.abs(X)
+    assert np.all(np.abs(G - ref) <= 2e-6 * absref + 1e-30)
+    assert np.array_equal(G, G.T)
+    G0 = torch.full((n, n), 3.0, dtype=torch.float64, device="cuda")
+    G2 = K.syrk_blocks(blocks, out=G0).cpu().numpy()
+    assert G2 is not None and np.allclose(G2 - 3.0, G, rtol=0, atol=1e-9 * np.abs(ref).max())
+    seq = K.syrk(blocks[0])
+    for B in blocks[1:]:
+        K.syrk(B, out=seq)
+    assert np.allclose(seq.cpu().numpy(), G, rtol=0, atol=1e-12 * np.abs(ref).max())

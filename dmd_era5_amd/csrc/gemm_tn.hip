@@ -589,7 +589,8 @@ struct Plan {
   size_t ws_bytes;
 };
 
-Plan make_plan(int64_t K, int64_t nrow, int64_t ncol, int syrk) {
+// share: number of equally sized row blocks that share the launch (batched SYRK)
+Plan make_plan(int64_t K, int64_t nrow, int64_t ncol, int syrk, int share = 1) {
   Plan pl;
   pl.tm = (!syrk && ((nrow - 1) % BT) < 64) ? 64 : BT;
   pl.ntr = (int)((nrow + pl.tm - 1) / pl.tm);
@@ -602,7 +603,11 @@ Plan make_plan(int64_t K, int64_t nrow, int64_t ncol, int syrk) {
   // L2 / Infinity Cache do not drift apart along K
   int64_t max_cps = 1024;  // 256 measured +0.8 % but needs 4x the workspace
   if (const char* e = getenv("DMDX_TN_MAX_CPS")) max_cps = atoll(e) > 0 ? atoll(e) : max_cps;
-  int64_t want = (20 * 512 + pl.ntiles - 1) / pl.ntiles;
+  // (few-tile products get their parallelism from K-splits alone, and every split costs a
+  // 128 KB partial tile: 4 rounds are enough there)
+  const int64_t rounds = pl.ntiles >= 64 ? 20 : 4;
+  const int64_t per_split = (int64_t)pl.ntiles * share;
+  int64_t want = (rounds * 512 + per_split - 1) / per_split;
   int64_t by_len = (pl.chunks_total + max_cps - 1) / max_cps;
   if (want < by_len) want = by_len;
   int64_t maxs = pl.chunks_total / 8;
@@ -672,7 +677,7 @@ size_t batch_group_ws(const int64_t* m, int nb, int64_t n) {
   size_t slabs = 0;
   Plan pl{};
   for (int j = 0; j < nb; ++j) {
-    pl = make_plan(m[j], n, n, 1);
+    pl = make_plan(m[j], n, n, 1, nb);
     slabs += (size_t)pl.nsplit;
   }
   return slabs * (size_t)pl.ntiles * BT * BT * sizeof(double);
@@ -699,7 +704,7 @@ int run_syrk_batch(const float* const* X, const int64_t* m, const int64_t* ldx, 
         dmdx_set_error("syrk_blocks: ldx >= 2^24 not supported (use smaller row blocks)");
         return DMDX_E_UNSUPPORTED;
       }
-      pl = make_plan(m[j0 + j], n, n, 1);
+      pl = make_plan(m[j0 + j], n, n, 1, nb);
       bt.X[j] = X[j0 + j];
       bt.ldx[j] = ld;
       bt.K[j] = m[j0 + j];

@@ -88,7 +88,7 @@ def main():
                    "note": "L2->fabric bytes (Infinity Cache hits included); FETCH_SIZE (KB) doubled per "
                            "MI355X_MICROARCH.md (gfx950 tallies the 128-B requests of a 16 B/lane stream at 64 B), "
                            "WRITE_SIZE exact.  The Gram re-reads every 128-column panel once per output tile that "
-                           "needs it, so L2 misses >> the 4.55 GB block; they are served by the Infinity Cache and "
+                           "needs it, so L2 misses >> the bytes of X; they are served by the Infinity Cache and "
                            "the kernel is MFMA-bound."}
     if sq:
         g = lambda k: sq.get(k, {}).get("per_launch_avg")

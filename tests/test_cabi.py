@@ -50,6 +50,11 @@ def test_argument_errors_are_reported_without_a_gpu(lib):
     assert rc == -1000
     rc = lib.dmdx_delay_shift_sum_f64(None, 4, 4, 2, None, 3, None, 0, None)
     assert rc == -1000
+    rc = lib.dmdx_eigh_small_f64(None, 4, 4, None, None, 4, None, None)
+    assert rc == -1000
+    rc = lib.dmdx_syrk_blocks_f32(None, None, None, 0, 8, None, 8, None, 0, 0, None, 0, None)
+    assert rc == -1000 and b"syrk_blocks" in lib.dmdx_last_error()
+    assert lib.dmdx_eigh_small_max_n() == 96
 
 
 def test_workspace_queries(lib):
@@ -59,6 +64,15 @@ def test_workspace_queries(lib):
     big = lib.dmdx_syrk_workspace_bytes(129780, 8760)
     assert 0 < big < 8 << 30
     assert lib.dmdx_gemm_tn_workspace_bytes(100000, 8760, 70) > 0
+    # batched K1: the slabs of all blocks of a launch (16 blocks at most) at once
+    import ctypes as C
+
+    ms = (C.c_int64 * 8)(*([129780] * 8))
+    batched = lib.dmdx_syrk_blocks_workspace_bytes(ms, 8, 8760)
+    assert batched % (128 * 128 * 8) == 0 and big <= batched <= 8 * big
+    many = (C.c_int64 * 40)(*([5000] * 40))
+    assert lib.dmdx_syrk_blocks_workspace_bytes(many, 40, 70) > 0
+    assert lib.dmdx_syrk_blocks_workspace_bytes(None, 0, 70) == 0
 
 
 def test_product_has_no_cpu_fallback():

@@ -1,20 +1,24 @@
 // K2: tall-skinny Y = X W on the fp32-input MFMA, X streamed once from HBM.
 //
 // X: m x n column-major (rows contiguous).  The MFMA A operand wants, per lane
-// (i = lane&31, h = lane>>5), the element A[i][k=h]: a lane loads FOUR
-// consecutive rows of column k0+2s+h with one global_load_dwordx4 and uses
-// register e as the A operand of row-block e, i.e. row-block e holds the rows
-// {row0 + 4*i + e}.  That is only a permutation of the rows inside the wave's
-// 128-row strip, undone when Y is stored (each lane then owns 4 consecutive
-// rows of its column -> one 16-byte store).  X therefore goes HBM -> VGPR ->
-// MFMA with full 16 B/lane loads and no LDS round trip (it has no reuse: every
-// workgroup owns its rows and all l columns).
-// W (n x l, small, L2 resident) is staged through LDS in 32-row chunks, read
-// back as the B operand with conflict-free ds_read_b32.
+// (i = lane&31, h = lane>>5), one element A[i][k]: a lane loads FOUR consecutive rows of one
+// column with a single 16-byte load and uses register e as the A operand of row-block e, i.e.
+// row-block e holds the rows {row0 + 4*i + e}.  That is only a permutation of the rows inside
+// the wave's 128-row strip, undone when Y is stored (each lane then owns 4 consecutive rows of
+// its column -> one 16-byte store).  X therefore goes HBM -> VGPR -> MFMA with full 16 B/lane
+// loads and no LDS round trip (it has no reuse: every workgroup owns its rows and all l columns).
+// W (n x l, small, L2 resident) is staged through LDS in 32-row chunks with K1's panel layout
+// ([column][32 k], 16-byte pieces XOR-swizzled) and read back with one conflict-free
+// ds_read_b128 per 4 MFMA k-steps: the 4 MFMAs j = 0..3 of step group t contract
+// k = 8t + 4h + j, the same permutation on both operands.
 //
-// Workgroup = 4 waves = 512 rows; per wave 128 rows x 32*C columns of Y in
-// 4*C accumulators; K loop over n in chunks of 32 (16 MFMA k-steps), X loads
-// issued half a chunk (8 steps = 8 KiB per wave) ahead of their use.
+// Workgroup = 4 waves = 512 rows; per wave 128 rows x 32*C columns of Y in 4*C accumulators;
+// K loop over n in chunks of 32 (4 step groups of 16 C MFMAs); full chunks load X with raw
+// buffer loads (descriptor + scalar column offset + 32-bit lane offset: no address VALU), each
+// group's registers refilled for the next chunk right after its MFMAs are issued (a whole chunk
+// of prefetch distance, pinned with sched_group_barrier -- the scheduler otherwise sinks the
+// loads to their uses), barrier before the last step group.  cfg2 pass at l = 62: 9.5 ms
+// (3.8 TB/s of X, 81 % of the 64-column MFMA bound); l = 128: 16.6 ms = 140 TFLOP/s.
 #include <type_traits>
 
 #include "dmdx_common.h"
@@ -24,15 +28,17 @@ namespace {
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int KB = 32;          // k rows per W chunk
-constexpr int LDW = KB + 1;     // padded LDS row of the transposed W chunk
 constexpr int ROWS_PER_WAVE = 128;
 constexpr int ROWS_PER_WG = 512;
 
 template <int C, bool ALIGNED>
-__global__ __launch_bounds__(256, (C <= 2 ? 2 : 1)) void skinny_kernel(
+__global__ __launch_bounds__(256, 1) void skinny_kernel(
     const float* __restrict__ X, int64_t m, int64_t n, int64_t ldx, const float* __restrict__ W,
     int64_t ldw, int l, float* __restrict__ Y, int64_t ldy) {
-  __shared__ float Ws[2][32 * C * LDW];
+  // W chunk image: [stage][column][32 k], unpadded; the 16-byte k-pieces of a column are stored
+  // at piece index q ^ swz(column) so that the ds_read_b128 fragment reads below (32 columns x 2
+  // pieces per wave) are bank-conflict free -- the layout of K1's operand panels
+  __shared__ __attribute__((aligned(16))) float Ws[2][32 * C * KB];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -41,7 +47,7 @@ __global__ __launch_bounds__(256, (C <= 2 ? 2 : 1)) void skinny_kernel(
   const int64_t myrow = rowW + 4 * l31;
   // Loads are never guarded: out-of-range rows / columns are CLAMPED onto valid
   // addresses instead (their products are multiplied by zero-padded W rows, or
-  // land in accumulator rows that are never stored).  FAST requires m % 4 == 0
+  // land in accumulator rows that are never stored).  ALIGNED requires m % 4 == 0
   // and 16-byte aligned bases / leading dimensions (checked by the host).
   int64_t crow = myrow;
   if (ALIGNED) {
@@ -49,18 +55,18 @@ __global__ __launch_bounds__(256, (C <= 2 ? 2 : 1)) void skinny_kernel(
   } else {
     if (crow >= m) crow = 0;         // partial lanes keep their rows (element guards)
   }
-  // per-lane 32-bit element offsets (host guarantees m + ldx < 2^29); the column
-  // base ku*ldx is wave-uniform and stays in SGPRs (saddr addressing)
-  const unsigned loff0 = (unsigned)crow;
-  const unsigned loff = (unsigned)(crow + (int64_t)lh * ldx);
-  const int64_t ku_max = (n - 1) & ~(int64_t)1;  // last even column index
-  // fast path (every column of the iteration in range): raw buffer loads -- a descriptor at
-  // the chunk's first column (SGPRs), the column as a scalar byte offset, the lane's rows as
-  // this 32-bit per-lane byte offset: no VALU and no 64-bit arithmetic per load
-  const unsigned loffb = 4u * loff;
+  // k order: the 4 MFMAs j = 0..3 of step group t contract k = 8t + 4h + j (h = lane >> 5) --
+  // the same permutation on both operands, so one 16-byte LDS read of W feeds 4 MFMAs (as in K1).
+  // The lane's X column for (t, j) is k0 + 8t + j + 4h: a uniform column offset plus this
+  // per-lane 32-bit byte offset (host guarantees m + 4 ldx < 2^29).
+  const unsigned loffb = 4u * (unsigned)(crow + (int64_t)(4 * lh) * ldx);
   const char* Xbytes = reinterpret_cast<const char*>(X);
   const int64_t ldxb = 4 * ldx;
-  const bool fast_ok = 2 * KB * ldxb < (int64_t(1) << 31);  // scalar byte offsets stay 32-bit
+  // fast path (every column of the iteration inside the matrix): raw buffer loads -- a
+  // descriptor at the chunk's first column (SGPRs), the column as a scalar byte offset, the
+  // lane's rows as the 32-bit per-lane byte offset: no VALU, no 64-bit arithmetic per load
+  const bool fast_ok = 2 * KB * ldxb < (int64_t(1) << 31) &&  // scalar byte offsets stay 32-bit
+                       (int64_t)l * ldw * 4 < (int64_t(1) << 31);
 
   f32x16 acc[4][C];
 #pragma unroll
@@ -70,29 +76,21 @@ __global__ __launch_bounds__(256, (C <= 2 ? 2 : 1)) void skinny_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[e][c][r] = 0.f;
 
-  // ku: wave-uniform even k (the lane's own column is ku + lh)
-  auto load_x = [&](int64_t ku) -> f32x4 {
-    const int64_t kc = ku < ku_max ? ku : ku_max;      // scalar clamp
-    const float* q = X + kc * ldx;                       // uniform base
-    const unsigned off = (kc + lh < n) ? loff : loff0;   // odd-n last column
-#if defined(DMDX_K2_ABL) && DMDX_K2_ABL == 2   /* timing only: no X loads */
+  // slow path (tail chunks, unaligned operands): kcol = uniform column of lane half 0
+  auto load_x = [&](int64_t kcol) -> f32x4 {
+    const int64_t ka = kcol < n ? kcol : n - 1, kb = kcol + 4 < n ? kcol + 4 : n - 1;  // scalar clamps
+    const float* q = X + (lh ? kb : ka) * ldx + crow;
     if (ALIGNED) {
-      f32x4 v = {(float)off, (float)kc, 1.f, 2.f};
-      asm volatile("" : "+v"(v));
-      return v;
-    }
-#endif
-    if (ALIGNED) {
-      return *reinterpret_cast<const f32x4*>(q + off);
+      return *reinterpret_cast<const f32x4*>(q);
     } else {
       f32x4 v;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = (crow + e < m) ? q[off + e] : 0.f;
+      for (int e = 0; e < 4; ++e) v[e] = (crow + e < m) ? q[e] : 0.f;
       return v;
     }
   };
 
-  // W staging: C pieces of 16 bytes per thread per chunk
+  // W staging: C pieces of 16 bytes per thread per chunk (column wcol + 32 i, k-piece wq)
   const int wcol = tid >> 3, wq = tid & 7;
   f32x4 wreg[C];
   auto load_w = [&](int64_t k0) {
@@ -113,106 +111,134 @@ __global__ __launch_bounds__(256, (C <= 2 ? 2 : 1)) void skinny_kernel(
       wreg[i] = v;
     }
   };
+  // fast path (the whole chunk inside the matrix): one unguarded buffer load per piece; the
+  // columns >= l are clamped onto column l-1 (they only feed output columns that are never stored)
+  unsigned woffb[C];
+#pragma unroll
+  for (int i = 0; i < C; ++i) {
+    const int col = wcol + 32 * i < l ? wcol + 32 * i : l - 1;
+    woffb[i] = (unsigned)(((int64_t)col * ldw + 4 * wq) * 4);
+  }
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(W), 0, -1, 0x00020000);
+  auto load_w_fast = [&](int64_t k0) {
+#pragma unroll
+    for (int i = 0; i < C; ++i)
+      wreg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, (int)woffb[i], (int)(4 * k0), 0));
+  };
+  const int wslot = 4 * (wq ^ ((wcol >> 1) & 7));  // swz(wcol + 32 i) == swz(wcol)
   auto store_w = [&](int st) {
 #pragma unroll
-    for (int i = 0; i < C; ++i) {
-      float* d = &Ws[st][(wcol + 32 * i) * LDW + 4 * wq];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) d[e] = wreg[i][e];
-    }
+    for (int i = 0; i < C; ++i)
+      *reinterpret_cast<f32x4*>(&Ws[st][(wcol + 32 * i) * KB + wslot]) = wreg[i];
   };
 
+  // B fragments of step group t: lane (c = l31, h) reads the piece (2t + h) of column 32 cc + c
+  int foff[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) foff[t] = l31 * KB + 4 * ((2 * t + lh) ^ ((l31 >> 1) & 7));
+#define DMDX_READ_B(dst, st, t)                                                      \
+  do {                                                                               \
+    _Pragma("unroll") for (int cc = 0; cc < C; ++cc)                                 \
+        dst[cc] = *reinterpret_cast<const f32x4*>(&Ws[st][32 * cc * KB + foff[t]]);  \
+  } while (0)
+#if defined(DMDX_K2_ABL) && DMDX_K2_ABL == 1   /* timing only: no MFMAs */
+#define DMDX_GROUP(xr, bv)                                                           \
+  do {                                                                               \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) asm volatile("" ::"v"((xr)[j]));   \
+    _Pragma("unroll") for (int cc = 0; cc < C; ++cc) asm volatile("" ::"v"(bv[cc])); \
+  } while (0)
+#else
+  // one step group = 4 k-steps x 4 row-blocks x C column blocks = 16 C MFMAs on 4 X quads
+#define DMDX_GROUP(xr, bv)                                                           \
+  do {                                                                               \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j)                                    \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e)                                \
+            _Pragma("unroll") for (int cc = 0; cc < C; ++cc) acc[e][cc] =            \
+                __builtin_amdgcn_mfma_f32_32x32x2f32((xr)[j][e], bv[cc][j], acc[e][cc], 0, 0, 0); \
+    __builtin_amdgcn_sched_group_barrier(0x008, 16 * C, 0);                          \
+  } while (0)
+#endif
+
   const int nchunks = (int)((n + KB - 1) / KB);
-  f32x4 xa[8], xb[8];
+  f32x4 xq[4][4];   // X quads of the current chunk: [step group t][j] = lane columns k0 + 8 t + j + 4 h
+  f32x4 b0[C], b1[C];
 
   load_w(0);
   store_w(0);
 #pragma unroll
-  for (int s = 0; s < 8; ++s) xa[s] = load_x(2 * s);
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) xq[t][j] = load_x(8 * t + j);
   __syncthreads();
+  DMDX_READ_B(b0, 0, 0);
 
-  // One k-step = 4*C MFMAs on one X register quad and C values of W.  The W values of
-  // step s+1 are read from LDS before the MFMAs of step s are issued (bn), so the LDS
-  // latency is covered by the 4*C*64 matrix-pipe cycles of the step.
-#define DMDX_READ_B(dst, s_)                                                         \
-  do {                                                                               \
-    _Pragma("unroll") for (int cc = 0; cc < C; ++cc) dst[cc] = ws[32 * cc * LDW + 2 * (s_)]; \
-  } while (0)
-#if defined(DMDX_K2_ABL) && DMDX_K2_ABL == 1   /* timing only: no MFMAs */
-#define DMDX_STEP(xreg, bv)                                                          \
-  do {                                                                               \
-    asm volatile("" ::"v"(xreg));                                                    \
-    _Pragma("unroll") for (int cc = 0; cc < C; ++cc) asm volatile("" ::"v"(bv[cc])); \
-  } while (0)
-#else
-#define DMDX_STEP(xreg, bv)                                                          \
-  do {                                                                               \
-    _Pragma("unroll") for (int e = 0; e < 4; ++e)                                    \
-        _Pragma("unroll") for (int cc = 0; cc < C; ++cc) acc[e][cc] =                \
-            __builtin_amdgcn_mfma_f32_32x32x2f32(xreg[e], bv[cc], acc[e][cc], 0, 0, 0); \
-  } while (0)
-#endif
-
+  // Chunk c: as soon as the MFMAs of step group t have been issued, the X quads of group t of
+  // chunk c + 1 are loaded into the same registers (a whole chunk = 64 C MFMAs ahead of their
+  // use).  The W chunk c + 1 is loaded at the start and stored to the other LDS stage before the
+  // barrier, which sits BEFORE the last step group: the wave leaves it with 16 C MFMAs to issue
+  // while its first W fragment of chunk c + 1 is read.  W fragments of group t + 1 are read while
+  // the MFMAs of group t run.
   int cur = 0;
   auto chunk = [&](int c, auto fast_tag) {
     constexpr bool FAST = decltype(fast_tag)::value;
     const int64_t k0 = (int64_t)c * KB;
-    const bool has_next = c + 1 < nchunks;
+    // (a FAST chunk always has a successor: its own columns end at k0 + KB <= n - KB)
+    const bool has_next = FAST ? true : (c + 1 < nchunks);
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char*>(Xbytes + k0 * ldxb), 0, -1, 0x00020000);  // 4 GiB window at column k0
-    auto ld = [&](int koff) -> f32x4 {   // columns k0 + koff, k0 + koff + 1
-      if constexpr (FAST) {
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)loffb, koff * (int)ldxb, 0);
-        return __builtin_bit_cast(f32x4, v);
-      } else {
-        return load_x(k0 + koff);
+        const_cast<char*>(Xbytes + (k0 + KB) * ldxb), 0, -1, 0x00020000);  // 4 GiB window at column k0 + KB
+    auto reload = [&](int t) {   // group t of chunk c + 1: lane columns k0 + KB + 8 t + j + 4 h
+      if (!has_next) return;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if constexpr (FAST) {
+#if defined(DMDX_K2_ABL) && DMDX_K2_ABL == 2   /* timing only: no X loads */
+          f32x4 v = {(float)j, 1.f, 2.f, 3.f};
+          asm volatile("" : "+v"(v));
+          xq[t][j] = v;
+#else
+          xq[t][j] = __builtin_bit_cast(
+              f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)loffb, (8 * t + j) * (int)ldxb, 0));
+#endif
+        } else {
+          xq[t][j] = load_x(k0 + KB + 8 * t + j);
+        }
       }
+      // (the VMEM groups pin the loads where they are written: left alone, the scheduler sinks
+      // them next to their first use and the prefetch distance is gone)
+      if constexpr (FAST) __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);
     };
-#pragma unroll
-    for (int s = 0; s < 8; ++s) xb[s] = ld(16 + 2 * s);
-    if (has_next) load_w(k0 + KB);
-
-    const float* ws = &Ws[cur][l31 * LDW + lh];
-    float b0[C], b1[C];
-    DMDX_READ_B(b0, 0);
-#pragma unroll
-    for (int s = 0; s < 8; s += 2) {
-      DMDX_READ_B(b1, s + 1);
-      __builtin_amdgcn_sched_group_barrier(0x100, (C + 1) / 2, 0);
-      DMDX_STEP(xa[s], b0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 4 * C, 0);
-      DMDX_READ_B(b0, s + 2);  // s + 2 == 8 is the first step of the second half
-      __builtin_amdgcn_sched_group_barrier(0x100, (C + 1) / 2, 0);
-      DMDX_STEP(xa[s + 1], b1);
-      __builtin_amdgcn_sched_group_barrier(0x008, 4 * C, 0);
-    }
     if (has_next) {
-#pragma unroll
-      for (int s = 0; s < 8; ++s) xa[s] = ld(KB + 2 * s);
+      if constexpr (FAST) load_w_fast(k0 + KB);  // FAST: columns k0 .. k0 + 2 KB - 1 exist
+      else load_w(k0 + KB);
     }
-#pragma unroll
-    for (int s = 0; s < 8; s += 2) {
-      DMDX_READ_B(b1, 8 + s + 1);
-      __builtin_amdgcn_sched_group_barrier(0x100, (C + 1) / 2, 0);
-      DMDX_STEP(xb[s], b0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 4 * C, 0);
-      if (s + 2 < 8) {
-        DMDX_READ_B(b0, 8 + s + 2);
-        __builtin_amdgcn_sched_group_barrier(0x100, (C + 1) / 2, 0);
-      }
-      DMDX_STEP(xb[s + 1], b1);
-      __builtin_amdgcn_sched_group_barrier(0x008, 4 * C, 0);
-    }
+    if constexpr (FAST) __builtin_amdgcn_sched_group_barrier(0x020, C, 0);
+    DMDX_READ_B(b1, cur, 1);
+    __builtin_amdgcn_sched_group_barrier(0x100, C, 0);
+    DMDX_GROUP(xq[0], b0);
+    reload(0);
+    DMDX_READ_B(b0, cur, 2);
+    __builtin_amdgcn_sched_group_barrier(0x100, C, 0);
+    DMDX_GROUP(xq[1], b1);
+    reload(1);
+    DMDX_READ_B(b1, cur, 3);
+    __builtin_amdgcn_sched_group_barrier(0x100, C, 0);
+    DMDX_GROUP(xq[2], b0);
+    reload(2);
     if (has_next) store_w(cur ^ 1);
-    __syncthreads();
+    __syncthreads();  // every wave has read stage `cur` for the last time; chunk c + 1 is in the other
     cur ^= 1;
+    if (has_next) DMDX_READ_B(b0, cur, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, C, 0);
+    DMDX_GROUP(xq[3], b1);
+    reload(3);
   };
   int c = 0;
   if (ALIGNED && fast_ok)  // every X column these iterations load (up to k0 + 2 KB - 1) is inside the matrix
     for (; (int64_t)(c + 2) * KB <= n; ++c) chunk(c, std::true_type{});
   for (; c < nchunks; ++c) chunk(c, std::false_type{});
 #undef DMDX_READ_B
-#undef DMDX_STEP
+#undef DMDX_GROUP
 
   // ---- epilogue: lane (j = l31, h) holds, for register r, MFMA row
   // i_m = (r&3) + 8*(r>>2) + 4*h of each row-block e  ->  global rows
@@ -264,7 +290,7 @@ extern "C" int dmdx_gemm_nn_skinny_f32(const float* X, int64_t m, int64_t n, int
   DMDX_CHECK_ARG(m >= 1 && n >= 1 && l >= 1, "skinny: bad shape m=%lld n=%lld l=%lld",
                  (long long)m, (long long)n, (long long)l);
   DMDX_CHECK_ARG(ldx >= 1 && ldw >= n && ldy >= m, "skinny: bad leading dimension");
-  DMDX_CHECK_ARG(m + ldx < (1ll << 29), "skinny: m + ldx >= 2^29 not supported");
+  DMDX_CHECK_ARG(m + 4 * ldx < (1ll << 29), "skinny: m + 4 ldx >= 2^29 not supported");
   hipStream_t st = (hipStream_t)stream;
   // column groups of at most 128 (4 MFMA blocks); X is re-read per group
   for (int64_t c0 = 0; c0 < l; c0 += 128) {

@@ -603,9 +603,13 @@ Plan make_plan(int64_t K, int64_t nrow, int64_t ncol, int syrk, int share = 1) {
   // L2 / Infinity Cache do not drift apart along K
   int64_t max_cps = 1024;  // 256 measured +0.8 % but needs 4x the workspace
   if (const char* e = getenv("DMDX_TN_MAX_CPS")) max_cps = atoll(e) > 0 ? atoll(e) : max_cps;
-  // (few-tile products get their parallelism from K-splits alone, and every split costs a
-  // 128 KB partial tile: 4 rounds are enough there)
-  const int64_t rounds = pl.ntiles >= 64 ? 20 : 4;
+  // Rounds of 512 resident workgroups to aim at.  Every split costs a partial tile (written,
+  // then read by the reduce kernel): many rounds only pay where the tiles are many and the
+  // operands are re-read from L2 anyway (big SYRK); few-tile products and the HBM-streaming
+  // X^T Y / Q^T X products (every X panel is read once) want few, long units
+  // (cfg2 randomized: K3 97.6 ms at 20 rounds, 91.5 at 4..8; l x l Grams 12.5 -> 7.6 ms at 2).
+  int64_t rounds = syrk ? (pl.ntiles >= 64 ? 20 : 2) : 6;
+  if (const char* e = getenv("DMDX_TN_ROUNDS")) rounds = atoll(e) > 0 ? atoll(e) : rounds;
   const int64_t per_split = (int64_t)pl.ntiles * share;
   int64_t want = (rounds * 512 + per_split - 1) / per_split;
   int64_t by_len = (pl.chunks_total + max_cps - 1) / max_cps;

@@ -390,4 +390,5 @@ def test_syrk_blocks_equals_sum_of_block_grams(K, sizes, n):
     seq = K.syrk(blocks[0])
     for B in blocks[1:]:
         K.syrk(B, out=seq)
-    assert np.allclose(seq.cpu().numpy(), G, rtol=0, atol=1e-12 * np.abs(ref).max())
+    # (the per-block and the batched launch cut K into different fp32 chains: same bound, not same bits)
+    assert np.all(np.abs(seq.cpu().numpy() - G) <= 4e-6 * absref + 1e-30)

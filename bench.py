@@ -48,15 +48,22 @@ WORKLOADS = {
 }
 
 
-def make_snapshot_blocks(m: int, n: int, seed: int, device) -> list[torch.Tensor]:
+def make_snapshot_blocks(m: int, n: int, seed: int, device, shard: int = 0) -> list[torch.Tensor]:
     """The snapshot matrix as row (space) blocks, each an (n, mb) fp32 device tensor
     (= the block's X^T), generated in time-slabs.  Row blocks keep the
-    column stride short (TLB reach, see dmd_era5_amd/svd.py)."""
+    column stride short (TLB reach, see dmd_era5_amd/svd.py).
+
+    ``shard``: row shard of ONE global matrix X = A diag(sigma) B^T + noise: the time factor B
+    (n x 64) comes from ``seed`` on every rank, the space factor A and the noise of this shard
+    from ``seed`` and ``shard`` -- the stacked matrix keeps rank 64 + noise whatever the number
+    of ranks (independent B per rank would make it rank 64 N, a different problem per N)."""
     from dmd_era5_amd.svd import split_rows
 
     g = torch.Generator(device=device).manual_seed(seed)
     rank = 64
     B = torch.randn((n, rank), generator=g, device=device, dtype=torch.float32)
+    if shard:
+        g = torch.Generator(device=device).manual_seed(seed + 1000003 * shard)
     sig = 100.0 * 0.9 ** torch.arange(rank, device=device, dtype=torch.float32)
     Bs = B * sig
     blocks = []
@@ -190,7 +197,7 @@ def main():
         comm = dsvd.Comm()
 
     m, n, r, desc = WORKLOADS[args.workload]
-    blocks = make_snapshot_blocks(m, n, 1234 + rank, device)
+    blocks = make_snapshot_blocks(m, n, 1234, device, shard=rank)
     for Xb in blocks:
         kern.row_center_scale_(Xb, False)
     torch.cuda.synchronize()

@@ -192,6 +192,9 @@ def main():
         else:
             dist.init_process_group(backend)
         comm = dsvd.TorchDistComm()
+        # bring the RCCL communicator up outside the timed region whatever --warmup is
+        dist.all_reduce(torch.zeros(1, device=device))
+        torch.cuda.synchronize()
     else:
         dist = None
         comm = dsvd.Comm()
@@ -204,6 +207,13 @@ def main():
 
     def step():
         return dsvd.svd_snapshots(blocks, r, comm=comm, kern=kern)
+
+    # library handles / code objects (rocBLAS, rocSOLVER, libdmdx) are created on first use: prime
+    # them on a toy problem so that --warmup 0 does not time their initialisation
+    toy = torch.randn((2048, 16384), device=device, dtype=torch.float32)
+    dsvd.svd_snapshots([toy[:, :8192].contiguous(), toy[:, 8192:].contiguous()], 8, kern=kern)
+    del toy
+    torch.cuda.synchronize()
 
     def barrier():
         if dist is not None:

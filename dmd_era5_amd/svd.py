@@ -158,14 +158,16 @@ def _eigh_desc(T: torch.Tensor, kern=None):
     return torch.flip(th, dims=(0,)), torch.flip(Z, dims=(1,))
 
 
-def top_eigh(G: torch.Tensor, l: int, method: str = "auto", tol: float = 1e-11,
+def top_eigh(G: torch.Tensor, l: int, method: str = "auto", tol: float = 1e-9,
              max_outer: int = 40, info: dict | None = None, kern=None):
     """Largest ``l`` eigenpairs of the symmetric PSD fp64 matrix ``G`` (n x n),
     eigenvalues descending.
 
     ``full``: torch.linalg.eigh.  ``krylov``: restarted block Krylov with
     Rayleigh-Ritz (only products G @ block, thin QRs and a (3b x 3b) eigh), run
-    until every wanted pair has residual <= tol * lambda_1, falling back to the
+    until every wanted pair has residual <= tol * lambda_1 (default 1e-9: the level of G's own
+    rounding error -- its entries are sums of fp32 products --, i.e. the pairs returned are exact
+    for a matrix as close to X^T X as G itself is), falling back to the
     full solver if that does not happen.  ``auto`` picks by size.
     """
     n = G.shape[0]
@@ -204,18 +206,19 @@ def top_eigh(G: torch.Tensor, l: int, method: str = "auto", tol: float = 1e-11,
             info["eig_residual"] = res
         return th[:l].contiguous(), Qn[:, :l].contiguous()
 
-    # Fast path: three more block power steps, then ONE (b x b) Rayleigh-Ritz.  With a steep
-    # spectrum behind the block (lambda_{b+1} << lambda_l: every low-rank + noise matrix, cfg2,
-    # where the fp32 rounding of G leaves a floor of ~1e-9 lambda_1) this reaches the tolerance
-    # for a fraction of the cost of a Krylov sweep ((3b x 3b) eigensolve, (n x 3b)
-    # orthonormalisation); otherwise its Ritz vectors are the start of the Krylov sweeps.
-    for _ in range(2):
+    # Fast path: block power steps with a (b x b) Rayleigh-Ritz (K7) after the 2nd and the 3rd
+    # step.  With a steep spectrum behind the block (lambda_{b+1} << lambda_l: every low-rank +
+    # noise matrix, cfg2, where the fp32 rounding of G leaves a floor of ~1e-9 lambda_1 and each
+    # step gains ~3 digits) this reaches the tolerance for a fraction of the cost of a Krylov
+    # sweep ((3b x 3b) eigensolve, (n x 3b) orthonormalisation); otherwise its Ritz vectors are
+    # the start of the Krylov sweeps.
+    for it in range(2):
         Q = _orth(G @ Q)
-    Y = G @ Q
-    th, Qn, res = ritz(Q, Y, b)
-    if res <= tol:
-        return done(th, Qn, res, "power", 1)
-    Q = Qn
+        Y = G @ Q
+        th, Qn, res = ritz(Q, Y, b)
+        if res <= tol:
+            return done(th, Qn, res, "power", it + 1)
+        Q = Qn
 
     def orth_against(Y, P):
         """Orthonormal basis of the part of span(Y) outside span(P) (P orthonormal): block

@@ -58,6 +58,17 @@ def main():
     os.makedirs(out, exist_ok=True)
     if os.path.exists(os.path.join(raw, "bench_default.json")):
         shutil.copy(os.path.join(raw, "bench_default.json"), os.path.join(out, f"{tag}_bench_default.json"))
+    if os.path.exists(os.path.join(raw, "bench_randomized.json")):
+        shutil.copy(os.path.join(raw, "bench_randomized.json"), os.path.join(out, f"{tag}_bench_randomized.json"))
+    fr = find(os.path.join(raw, "stats_rand"), "kernel_stats.csv")
+    if fr:
+        rr = list(csv.DictReader(open(fr)))
+        rr.sort(key=lambda r: -float(r.get("TotalDurationNs", 0) or 0))
+        if rr:
+            with open(os.path.join(out, f"{tag}_bench_randomized_kernel_stats.csv"), "w", newline="") as g:
+                w = csv.DictWriter(g, fieldnames=list(rr[0].keys()))
+                w.writeheader()
+                w.writerows(rr[:20])
     f, rows = kernel_stats(raw)
     rows.sort(key=lambda r: -float(r.get("TotalDurationNs", 0) or 0))
     top = rows[:12]

@@ -64,8 +64,10 @@ struct TnParams {
 // [slab_begin[j], slab_begin[j+1]); the reduce kernel sums all slabs.
 constexpr int MAXB = 16;
 struct TnBatch {
-  const float* X[MAXB];
-  int64_t ldx[MAXB];
+  const float* A[MAXB];   // D rows <- columns of A_j; SYRK: A_j == B_j == X_j
+  const float* B[MAXB];   // D cols <- columns of B_j
+  int64_t lda[MAXB];
+  int64_t ldb[MAXB];
   int64_t K[MAXB];
   int chunks_total[MAXB];
   int chunks_per_split[MAXB];
@@ -490,10 +492,12 @@ __global__ __launch_bounds__(NTH, 2) void gemm_tn_partial_kernel(TnParams p) {
   tn_unit<DMA, ABL, SK>(p, split, ta * (SK ? 64 : BT), tb * BT, Pt, lds);
 }
 
-// SYRK over a batch of row blocks (TnBatch); p carries what the blocks share (n, tiles, P).
-template <bool DMA>
+// D (+)= sum_j A_j^T B_j over a batch of row blocks (TnBatch); p carries what the blocks share
+// (shape of D, tiles, P).  SYRK: A_j == B_j, triangle tiles.
+template <bool DMA, bool SK = false>
 __global__ __launch_bounds__(NTH, 2) void syrk_batch_kernel(TnParams p, TnBatch bt) {
-  __shared__ __attribute__((aligned(16))) float lds[2 * (BT + BT) * BK];
+  constexpr int TM = SK ? 64 : BT;
+  __shared__ __attribute__((aligned(16))) float lds[2 * (TM + BT) * BK];
   const int b = blockIdx.x;
   int j = 0;
   while (j + 1 < bt.nblocks && b >= bt.unit_begin[j + 1]) ++j;
@@ -504,14 +508,16 @@ __global__ __launch_bounds__(NTH, 2) void syrk_batch_kernel(TnParams p, TnBatch 
   const int split = pos / p.ntiles;
   const int tile = pos - split * p.ntiles;
   int ta, tb;
-  decode_tri(tile, p.ntr, ta, tb);
-  p.A = p.B = bt.X[j];
-  p.lda = p.ldb = bt.ldx[j];
+  decode_tile(p, tile, ta, tb);
+  p.A = bt.A[j];
+  p.B = bt.B[j];
+  p.lda = bt.lda[j];
+  p.ldb = bt.ldb[j];
   p.K = bt.K[j];
   p.chunks_total = bt.chunks_total[j];
   p.chunks_per_split = bt.chunks_per_split[j];
-  double* Pt = p.P + ((size_t)(bt.slab_begin[j] + split) * p.ntiles + tile) * (BT * BT);
-  tn_unit<DMA, 0, false>(p, split, ta * BT, tb * BT, Pt, lds);
+  double* Pt = p.P + ((size_t)(bt.slab_begin[j] + split) * p.ntiles + tile) * (TM * BT);
+  tn_unit<DMA, 0, SK>(p, split, ta * TM, tb * BT, Pt, lds);
 }
 
 // Sum the K-splits in fp64 and scatter the tile into D (row-major view:
@@ -676,25 +682,25 @@ int run_tn(const float* A, int64_t lda, const float* B, int64_t ldb, int64_t K, 
   return 0;
 }
 
-// ---- batched SYRK: G (+)= sum_j X_j^T X_j, blocks in groups of MAXB per launch
-size_t batch_group_ws(const int64_t* m, int nb, int64_t n) {
+// ---- batched products: D (+)= sum_j A_j^T B_j, blocks in groups of MAXB per launch
+size_t batch_group_ws(const int64_t* K, int nb, int64_t nrow, int64_t ncol, int syrk) {
   size_t slabs = 0;
   Plan pl{};
   for (int j = 0; j < nb; ++j) {
-    pl = make_plan(m[j], n, n, 1, nb);
+    pl = make_plan(K[j], nrow, ncol, syrk, nb);
     slabs += (size_t)pl.nsplit;
   }
-  return slabs * (size_t)pl.ntiles * BT * BT * sizeof(double);
+  return slabs * (size_t)pl.ntiles * pl.tm * BT * sizeof(double);
 }
 
-int run_syrk_batch(const float* const* X, const int64_t* m, const int64_t* ldx, int nblocks, int64_t n,
-                   double* G64, int64_t ldg, float* G32, int64_t ldg32, int accumulate, void* ws,
-                   size_t ws_bytes, hipStream_t stream) {
+int run_batch(const float* const* A, const int64_t* lda, const float* const* B, const int64_t* ldb,
+              const int64_t* K, int nblocks, int64_t nrow, int64_t ncol, int syrk, double* D64, int64_t ld64,
+              float* D32, int64_t ld32, int accumulate, void* ws, size_t ws_bytes, hipStream_t stream) {
   for (int j0 = 0; j0 < nblocks; j0 += MAXB) {
     const int nb = nblocks - j0 < MAXB ? nblocks - j0 : MAXB;
-    const size_t need = batch_group_ws(m + j0, nb, n);
+    const size_t need = batch_group_ws(K + j0, nb, nrow, ncol, syrk);
     if (ws == nullptr || ws_bytes < need) {
-      dmdx_set_error("syrk_blocks: workspace %zu bytes < required %zu", ws_bytes, need);
+      dmdx_set_error("blocks: workspace %zu bytes < required %zu", ws_bytes, need);
       return DMDX_E_WORKSPACE;
     }
     TnBatch bt{};
@@ -703,15 +709,17 @@ int run_syrk_batch(const float* const* X, const int64_t* m, const int64_t* ldx, 
     int units = 0, slabs = 0;
     Plan pl{};
     for (int j = 0; j < nb; ++j) {
-      const int64_t ld = ldx[j0 + j];
-      if (ld >= (int64_t(1) << 24)) {
-        dmdx_set_error("syrk_blocks: ldx >= 2^24 not supported (use smaller row blocks)");
+      const int64_t la = lda[j0 + j], lb = ldb[j0 + j];
+      if (la >= (int64_t(1) << 24) || lb >= (int64_t(1) << 24)) {
+        dmdx_set_error("blocks: leading dimension >= 2^24 not supported (use smaller row blocks)");
         return DMDX_E_UNSUPPORTED;
       }
-      pl = make_plan(m[j0 + j], n, n, 1, nb);
-      bt.X[j] = X[j0 + j];
-      bt.ldx[j] = ld;
-      bt.K[j] = m[j0 + j];
+      pl = make_plan(K[j0 + j], nrow, ncol, syrk, nb);
+      bt.A[j] = A[j0 + j];
+      bt.B[j] = B[j0 + j];
+      bt.lda[j] = la;
+      bt.ldb[j] = lb;
+      bt.K[j] = K[j0 + j];
       bt.chunks_total[j] = pl.chunks_total;
       bt.chunks_per_split[j] = pl.chunks_per_split;
       bt.nsplit[j] = pl.nsplit;
@@ -720,22 +728,29 @@ int run_syrk_batch(const float* const* X, const int64_t* m, const int64_t* ldx, 
       const int u = pl.nsplit * pl.ntiles;
       units += (j + 1 < nb) ? (u + 511) / 512 * 512 : u;
       slabs += pl.nsplit;
-      aligned = aligned && (ld % 4 == 0) && dmdx_aligned16(X[j0 + j]) && ld < (int64_t(1) << 22);
+      aligned = aligned && (la % 4 == 0) && (lb % 4 == 0) && dmdx_aligned16(A[j0 + j]) &&
+                dmdx_aligned16(B[j0 + j]) && la < (int64_t(1) << 22) && lb < (int64_t(1) << 22);
     }
     bt.unit_begin[nb] = units;
     bt.slab_begin[nb] = slabs;
     bt.nblocks = nb;
-    p.nrow = p.ncol = (int)n;
-    p.ntr = pl.ntr; p.ntc = pl.ntc; p.ntiles = pl.ntiles; p.syrk = 1;
+    p.nrow = (int)nrow;
+    p.ncol = (int)ncol;
+    p.ntr = pl.ntr; p.ntc = pl.ntc; p.ntiles = pl.ntiles; p.syrk = syrk;
     p.nsplit = slabs;
     p.P = reinterpret_cast<double*>(ws);
-    if (aligned)
-      hipLaunchKernelGGL(syrk_batch_kernel<true>, dim3((unsigned)units), dim3(NTH), 0, stream, p, bt);
-    else
-      hipLaunchKernelGGL(syrk_batch_kernel<false>, dim3((unsigned)units), dim3(NTH), 0, stream, p, bt);
+    const dim3 grid((unsigned)units);
+    if (pl.tm == 64) {
+      if (aligned) hipLaunchKernelGGL((syrk_batch_kernel<true, true>), grid, dim3(NTH), 0, stream, p, bt);
+      else hipLaunchKernelGGL((syrk_batch_kernel<false, true>), grid, dim3(NTH), 0, stream, p, bt);
+    } else {
+      if (aligned) hipLaunchKernelGGL((syrk_batch_kernel<true, false>), grid, dim3(NTH), 0, stream, p, bt);
+      else hipLaunchKernelGGL((syrk_batch_kernel<false, false>), grid, dim3(NTH), 0, stream, p, bt);
+    }
     DMDX_LAUNCH_CHECK();
-    hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3(pl.ntiles * 16), dim3(256), 0, stream, p.P, slabs, pl.ntiles,
-                       pl.ntr, pl.ntc, 1, (int)n, (int)n, G64, ldg, G32, ldg32, (accumulate || j0 > 0) ? 1 : 0, BT);
+    hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3(pl.ntiles * (pl.tm / 32) * 4), dim3(256), 0, stream, p.P, slabs,
+                       pl.ntiles, pl.ntr, pl.ntc, syrk, (int)nrow, (int)ncol, D64, ld64, D32, ld32,
+                       (accumulate || j0 > 0) ? 1 : 0, pl.tm);
     DMDX_LAUNCH_CHECK();
   }
   return 0;
@@ -779,7 +794,7 @@ size_t dmdx_syrk_blocks_workspace_bytes(const int64_t* m, int nblocks, int64_t n
   for (int j0 = 0; j0 < nblocks; j0 += MAXB) {
     for (int j = j0; j < nblocks && j < j0 + MAXB; ++j)
       if (m[j] < 1) return 0;
-    const size_t g = batch_group_ws(m + j0, nblocks - j0 < MAXB ? nblocks - j0 : MAXB, n);
+    const size_t g = batch_group_ws(m + j0, nblocks - j0 < MAXB ? nblocks - j0 : MAXB, n, n, 1);
     if (g > need) need = g;
   }
   return need;
@@ -792,8 +807,8 @@ int dmdx_syrk_blocks_f32(const float* const* X, const int64_t* m, const int64_t*
   DMDX_CHECK_ARG(n >= 1 && n < (1 << 30) && ldg >= n && (!G32 || ldg32 >= n), "syrk_blocks: bad n / ldg");
   for (int j = 0; j < nblocks; ++j)
     DMDX_CHECK_ARG(X[j] && m[j] >= 1 && ldx[j] >= 1, "syrk_blocks: bad block %d", j);
-  return run_syrk_batch(X, m, ldx, nblocks, n, G64, ldg, G32, ldg32, accumulate, workspace, workspace_bytes,
-                        (hipStream_t)stream);
+  return run_batch(X, ldx, X, ldx, m, nblocks, n, n, 1, G64, ldg, G32, ldg32, accumulate, workspace,
+                   workspace_bytes, (hipStream_t)stream);
 }
 
 size_t dmdx_gemm_tn_workspace_bytes(int64_t K, int64_t na, int64_t nb) {
@@ -814,6 +829,32 @@ int dmdx_gemm_tn_f32(const float* A, int64_t lda, const float* B, int64_t ldb, i
   // column-major C[a + b*ldc] == row-major D[b][a]: D rows <- B columns, D cols <- A columns
   return run_tn(B, ldb, A, lda, K, nb, na, 0, C64, ldc, C32, ldc32, accumulate, workspace, workspace_bytes,
                 (hipStream_t)stream);
+}
+
+size_t dmdx_gemm_tn_blocks_workspace_bytes(const int64_t* K, int nblocks, int64_t na, int64_t nb) {
+  if (!K || nblocks <= 0 || na <= 0 || nb <= 0) return 0;
+  size_t need = 0;
+  for (int j0 = 0; j0 < nblocks; j0 += MAXB) {
+    for (int j = j0; j < nblocks && j < j0 + MAXB; ++j)
+      if (K[j] < 1) return 0;
+    const size_t g = batch_group_ws(K + j0, nblocks - j0 < MAXB ? nblocks - j0 : MAXB, nb, na, 0);
+    if (g > need) need = g;
+  }
+  return need;
+}
+
+int dmdx_gemm_tn_blocks_f32(const float* const* A, const int64_t* lda, const float* const* B,
+                            const int64_t* ldb, const int64_t* K, int nblocks, int64_t na, int64_t nb,
+                            double* C64, int64_t ldc, float* C32, int64_t ldc32, int accumulate,
+                            void* workspace, size_t workspace_bytes, void* stream) {
+  DMDX_CHECK_ARG(A && B && lda && ldb && K && C64 && nblocks >= 1, "gemm_tn_blocks: null pointer or no blocks");
+  DMDX_CHECK_ARG(na >= 1 && nb >= 1 && na < (1 << 30) && nb < (1 << 30) && ldc >= na && (!C32 || ldc32 >= na),
+                 "gemm_tn_blocks: bad shape / ldc");
+  for (int j = 0; j < nblocks; ++j)
+    DMDX_CHECK_ARG(A[j] && B[j] && K[j] >= 1 && lda[j] >= 1 && ldb[j] >= 1, "gemm_tn_blocks: bad block %d", j);
+  // column-major C[a + b*ldc] == row-major D[b][a]: D rows <- B columns, D cols <- A columns
+  return run_batch(B, ldb, A, lda, K, nblocks, nb, na, 0, C64, ldc, C32, ldc32, accumulate, workspace,
+                   workspace_bytes, (hipStream_t)stream);
 }
 
 }  // extern "C"

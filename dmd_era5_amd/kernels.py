@@ -153,6 +153,39 @@ class HipKernels:
         _lib.check(rc, "dmdx_gemm_tn_f32")
         return (C64, C32) if want32 else C64
 
+    def gemm_tn_blocks(self, Ablocks, Bblocks, out: torch.Tensor | None = None) -> torch.Tensor:
+        """C (+)= sum_j A_j^T B_j over lists of K-contiguous row blocks (At_j: (na, K_j), Bt_j:
+        (nb, K_j) fp32), 16 blocks per launch.  Returns Ct (nb, na) fp64."""
+        import ctypes as C
+
+        if len(Ablocks) != len(Bblocks) or not Ablocks:
+            raise _lib.DmdxError("gemm_tn_blocks: two equally long, non-empty lists of blocks")
+        sa = [_check_mat(A, torch.float32, "gemm_tn_blocks A") for A in Ablocks]
+        sb = [_check_mat(B, torch.float32, "gemm_tn_blocks B") for B in Bblocks]
+        na, nb_ = sa[0][1], sb[0][1]
+        if any(x[1] != na for x in sa) or any(x[1] != nb_ for x in sb) or any(x[0] != y[0] for x, y in zip(sa, sb)):
+            raise _lib.DmdxError("gemm_tn_blocks: inconsistent block shapes")
+        dev = Ablocks[0].device
+        if out is not None:
+            if out.shape != (nb_, na) or out.dtype != torch.float64 or not out.is_contiguous():
+                raise _lib.DmdxError("gemm_tn_blocks: out must be a contiguous (nb, na) fp64 tensor")
+            C64 = out
+        else:
+            C64 = torch.empty((nb_, na), dtype=torch.float64, device=dev)
+        n = len(Ablocks)
+        pa = (C.c_void_p * n)(*[A.data_ptr() for A in Ablocks])
+        pb = (C.c_void_p * n)(*[B.data_ptr() for B in Bblocks])
+        la = (C.c_int64 * n)(*[x[2] for x in sa])
+        lb = (C.c_int64 * n)(*[x[2] for x in sb])
+        ks = (C.c_int64 * n)(*[x[0] for x in sa])
+        ws = self._workspace(dev, self._lib.dmdx_gemm_tn_blocks_workspace_bytes(ks, n, na, nb_))
+        rc = self._timed("gemm_tn_blocks", (sum(x[0] for x in sa), na, nb_, n), lambda: self._lib.dmdx_gemm_tn_blocks_f32(
+            pa, la, pb, lb, ks, n, na, nb_, _ptr(C64), na, None, 0, int(out is not None), _ptr(ws), ws.numel(),
+            self._stream()
+        ))
+        _lib.check(rc, "dmdx_gemm_tn_blocks_f32")
+        return C64
+
     # -- K2 -----------------------------------------------------------------
     def skinny(self, Xt: torch.Tensor, Wt: torch.Tensor) -> torch.Tensor:
         """Y = X W.  Xt: (n, m), Wt: (l, n) fp32 -> Yt: (l, m) fp32."""

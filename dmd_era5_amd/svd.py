@@ -283,9 +283,10 @@ def _gram_blocks(blocks, kern, comm: Comm) -> torch.Tensor:
 
 
 def _gemm_tn_blocks(Ablocks, Bblocks, kern, comm: Comm) -> torch.Tensor:
-    C = None
-    for A, B in zip(Ablocks, Bblocks):
-        C = kern.gemm_tn(A, B) if C is None else kern.gemm_tn(A, B, out=C)
+    if len(Ablocks) > 1:
+        C = kern.gemm_tn_blocks(list(Ablocks), list(Bblocks))
+    else:
+        C = kern.gemm_tn(Ablocks[0], Bblocks[0])
     return comm.allreduce_sum_(C)
 
 

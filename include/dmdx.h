@@ -80,6 +80,16 @@ int dmdx_gemm_tn_f32(const float* A, int64_t lda, const float* B, int64_t ldb,
                      double* C64, int64_t ldc, float* C32, int64_t ldc32, int accumulate,
                      void* workspace, size_t workspace_bytes, void* stream);
 
+/* K3 over lists of row blocks in ONE launch per 16 blocks:  C (+)= sum_j A_j^T B_j  (A_j: K[j] x na,
+ * lda[j]; B_j: K[j] x nb, ldb[j]; all five arrays live on the HOST).  The randomized path's
+ * Z = X^T Y and B = Q^T X are sums over the row blocks of X; per-block launches of this
+ * HBM-streaming product are only ~4 rounds of workgroups each. */
+size_t dmdx_gemm_tn_blocks_workspace_bytes(const int64_t* K, int nblocks, int64_t na, int64_t nb);
+int dmdx_gemm_tn_blocks_f32(const float* const* A, const int64_t* lda, const float* const* B,
+                            const int64_t* ldb, const int64_t* K, int nblocks, int64_t na, int64_t nb,
+                            double* C64, int64_t ldc, float* C32, int64_t ldc32, int accumulate,
+                            void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- K2: tall-skinny Y = X W -----------------------------------------------
  * X: m x n (ldx, rows > ldx allowed), W: n x l (ldw), Y: m x l (ldy), l <= 256.
  * U = X (V_r S^-1) of the method of snapshots and `A @ Q` of the range finder

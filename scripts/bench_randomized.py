@@ -37,7 +37,7 @@ rows = {"skinny": [], "gemm_tn": []}
 for name, shape, e0, e1 in events:
     if name == "skinny" and shape[1] == n:        # (m_b, n, l): X streamed
         rows["skinny"].append((shape[0], e0.elapsed_time(e1)))
-    elif name == "gemm_tn" and shape[0] > 4 * n:  # (K = m_b, na, nb): X streamed
+    elif name in ("gemm_tn", "gemm_tn_blocks") and shape[0] > 4 * n:  # (K, na, nb[, blocks]): X streamed
         rows["gemm_tn"].append((shape[0], e0.elapsed_time(e1)))
 out = {"metric": "randomized rank-r SVD GB/s on ERA5 snapshot matrix (X resident in HBM)",
        "value": m * n * 4.0 / dt / 1e9, "unit": "GB/s", "ms_per_step": dt * 1e3, "n_gpus": 1,

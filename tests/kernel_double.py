@@ -33,6 +33,12 @@ class CpuKernelDouble:
             C = out
         return (C, C.float()) if want32 else C
 
+    def gemm_tn_blocks(self, Ablocks, Bblocks, out=None):
+        Cm = out
+        for A, B in zip(Ablocks, Bblocks):
+            Cm = self.gemm_tn(A, B) if Cm is None else self.gemm_tn(A, B, out=Cm)
+        return Cm
+
     def skinny(self, Xt, Wt):
         return (Wt.to(torch.float64) @ Xt.to(torch.float64)).float()
 

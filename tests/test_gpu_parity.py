@@ -392,3 +392,21 @@ def test_syrk_blocks_equals_sum_of_block_grams(K, sizes, n):
         K.syrk(B, out=seq)
     # (the per-block and the batched launch cut K into different fp32 chains: same bound, not same bits)
     assert np.all(np.abs(seq.cpu().numpy() - G) <= 4e-6 * absref + 1e-30)
+
+
+@pytest.mark.parametrize("sizes,na,nb", [([5000, 3000, 4097], 60, 260), ([700] * 19, 70, 200), ([30001, 29999], 130, 129)])
+def test_gemm_tn_blocks_equals_sum_of_block_products(K, sizes, na, nb):
+    """dmdx_gemm_tn_blocks_f32 against the fp64 product of the stacked rows: ragged block sizes,
+    > 16 blocks, 64-row and 128-row tiles, accumulation into an existing C."""
+    rs = np.random.RandomState(sum(sizes) + na + nb)
+    As = [_rand(rs, m, na) for m in sizes]
+    Bs = [_rand(rs, m, nb) for m in sizes]
+    Ct = K.gemm_tn_blocks([_dev(a.T) for a in As], [_dev(b.T) for b in Bs]).cpu().numpy()   # (nb, na)
+    A, B = np.concatenate(As).astype(np.float64), np.concatenate(Bs).astype(np.float64)
+    ref = (A.T @ B).T
+    absref = (np.abs(A).T @ np.abs(B)).T
+    assert Ct.shape == (nb, na)
+    assert np.all(np.abs(Ct - ref) <= 2e-6 * absref + 1e-30)
+    C0 = torch.full((nb, na), -2.0, dtype=torch.float64, device="cuda")
+    C2 = K.gemm_tn_blocks([_dev(a.T) for a in As], [_dev(b.T) for b in Bs], out=C0).cpu().numpy()
+    assert np.allclose(C2 + 2.0, Ct, rtol=0, atol=1e-9 * np.abs(ref).max())

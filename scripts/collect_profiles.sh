@@ -29,5 +29,5 @@ rocprofv3 --kernel-trace --stats -d "$OUT/stats_rand" --output-format csv -- pyt
 echo "[prof] summarize"
 python3 scripts/summarize_profiles.py "$OUT" "$ROOT/gpurun_out/profiles_$TAG" "$TAG"
 # the raw traces are large: keep only the small summaries + logs in gpurun_out/
-find "$OUT" -name "*.csv" -size +2M -delete
+find "$OUT" -name "*.csv" -size +20M -delete
 echo "[prof] done"

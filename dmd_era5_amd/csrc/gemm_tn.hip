@@ -24,10 +24,22 @@
 //   writes D (both triangles in SYRK mode).  Row blocks are accumulated into D
 //   in fp64 (`accumulate`).
 //
+//   Chunk pipeline: both stages filled up front; chunk c runs k-steps 0..2, then the
+//   barrier, then k-step 3 (its fragments are already in registers), the refill of the
+//   freed stage with chunk c+2 and the first fragment reads of chunk c+1.
+//
 // L2 locality: units are ordered tile-fastest inside a K-split, the tiles of
-// the triangle are enumerated in 4-row super-rows, column by column, so 32
-// consecutive units form a 4x8 patch of tiles; blockIdx is remapped so that
-// the 32 blocks that land on one XCD (blockIdx % 8 equal) take one patch.
+// the triangle are enumerated in 8-row super-rows, column by column, so 64
+// consecutive units form an 8x8 patch of tiles; blockIdx is remapped so that
+// the 64 blocks of a group of 512 that land on one XCD (blockIdx % 8 equal)
+// take one patch (xcd_unit).
+//
+// Entry points: dmdx_syrk_f32 / dmdx_gemm_tn_f32 (one pair of operands per launch) and
+// dmdx_syrk_blocks_f32 / dmdx_gemm_tn_blocks_f32 (the sum over up to 16 row blocks per
+// launch, syrk_batch_kernel); all of them run tn_unit, the reduce kernel sums the K-splits.
+// Environment knobs (tuning / diagnosis only): DMDX_TN_MAX_CPS (chunks per unit, default 1024),
+// DMDX_TN_ROUNDS (rounds of 512 workgroups the K-splits aim at), DMDX_TN_ABLATE (timing-only
+// ablations of the single-launch kernel: results are wrong).
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -56,8 +68,8 @@ struct TnParams {
   double* P;        // [slab][ntiles][tile rows x 128] fp64 partial tiles; slab = K-split (of a block)
 };
 
-// A batch of SYRK row blocks in one launch: the Gram of a row-blocked snapshot matrix is the
-// sum over its blocks, and one launch per block leaves the GPU draining / refilling 8 times
+// A batch of row blocks in one launch: the Gram of a row-blocked snapshot matrix (and X^T Y) is
+// the sum over its blocks, and one launch per block leaves the GPU draining / refilling 8 times
 // (last partial round of units, reduce kernel, launch gap: ~1.5 % at cfg2).  Block j owns the
 // grid range [unit_begin[j], unit_begin[j+1]) (padded to multiples of 512 so that the XCD
 // patch mapping stays aligned; padding blocks exit at once) and the partial-tile slabs
@@ -77,7 +89,7 @@ struct TnBatch {
   int nblocks;
 };
 
-// upper-triangle tile enumeration: super-rows of 4 tile rows, column-major
+// upper-triangle tile enumeration: super-rows of SR tile rows, column-major
 // inside a super-row (see header comment).
 constexpr int SR = 8;  // tile rows per super-row: 64 consecutive tiles ~ an 8x8 patch
 __device__ __host__ inline void decode_tri(int t, int nt, int& ta, int& tb) {

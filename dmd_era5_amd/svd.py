@@ -353,6 +353,9 @@ def svd_snapshots(Xt, n_components: int, delay: int = 1, oversample: int | None 
     t0 = _sync_time(dev) if timings else 0.0
 
     G = _gram_blocks(blocks, kern, comm)
+    if not bool(torch.isfinite(torch.diagonal(G)).all()):
+        # NaN / Inf in X: what np.linalg.svd (the reference's call, era5_svd.py:251) reports
+        raise np.linalg.LinAlgError("SVD did not converge")
     if delay > 1:
         G = kern.delay_shift_sum(G, delay)
     nd = G.shape[0]

@@ -161,3 +161,12 @@ def test_row_sharded_two_ranks_equal_single_rank(svd_type):
     assert np.allclose(out[0][1], ref.s.numpy(), rtol=1e-8)
     assert np.allclose(out[0][3], ref.Vh.numpy(), atol=1e-7)
     assert np.allclose(U, ref.Ut.numpy(), atol=1e-6)           # includes the global sign flip
+
+
+def test_non_finite_input_raises_like_numpy():
+    """np.linalg.svd (the reference's call) raises LinAlgError on NaN input; so does the engine,
+    instead of iterating on a Gram matrix full of NaNs."""
+    X = orc.lowrank_matrix(512, 40, 10, 1)
+    X[17, 3] = np.nan
+    with pytest.raises(np.linalg.LinAlgError, match="did not converge"):
+        dsvd.svd_snapshots(_xt(X), 5, kern=K)

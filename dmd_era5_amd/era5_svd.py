@@ -329,6 +329,10 @@ def _device_pipeline(ds: Dataset, parsed_config: dict):
     if parsed_config["svd_type"] == "standard":
         log_and_print(logger, "Performing standard SVD...")
         res = dsvd.svd_snapshots(blocks, k, delay=d)
+        if res.info.get("mean_deflated"):
+            log_and_print(logger, "Un-centred data: SVD of the centred matrix + rank-one update for the time mean.")
+        if res.info.get("warning"):
+            log_and_print(logger, "WARNING: " + res.info["warning"])
         log_and_print(logger, "Standard SVD complete.")
     else:
         log_and_print(logger, "Performing randomized SVD...")

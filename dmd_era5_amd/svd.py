@@ -336,20 +336,108 @@ def _sync_time(device) -> float:
 # ---------------------------------------------------------------------------
 # "standard": method of snapshots
 # ---------------------------------------------------------------------------
+def _time_mean_dominates(blocks, comm: Comm) -> bool:
+    """Does the per-row time mean carry most of the energy of X (un-centred fields such as
+    temperature ~ 280 K + O(10) K anomalies)?  Estimated on up to 2048 rows of every block."""
+    acc = torch.zeros(2, dtype=torch.float64, device=blocks[0].device)
+    for B in blocks:
+        var, mean = torch.var_mean(B[:, : min(2048, B.shape[1])].double(), dim=0, unbiased=False)
+        acc[0] += (mean * mean).sum()
+        acc[1] += var.sum()
+    comm.allreduce_sum_(acc)
+    return bool(acc[0] > acc[1])
+
+
+def _svd_snapshots_mean_deflated(blocks, n_components, oversample, flip_sign, comm, kern, eig_method,
+                                 timings) -> SvdResult:
+    """SVD of X = Xc + mu 1^T through the SVD of the row-centred Xc and a rank-one update.
+
+    The Gram route squares the condition number: with a dominant time mean (s_1 ~ 1e4 s_2 for
+    un-centred temperature) the wanted trailing eigenvalues of X^T X drown in the rounding of its
+    fp32 products.  Xc is well conditioned, and since Xc 1 = 0 the ones vector is orthogonal to
+    every right singular vector of Xc:  X = [Uc, p^] K [Vc, 1/sqrt(n)]^T  with
+    K = [[Sc, a sqrt(n)], [0, |p| sqrt(n)]],  a = Uc^T mu,  p = mu - Uc a,  exactly for the kept
+    modes of Xc.  The blocks are centred in place (K5) and restored before returning."""
+    dev = blocks[0].device
+    n = blocks[0].shape[0]
+    t0 = _sync_time(dev) if timings else 0.0
+    mus = [kern.row_center_scale_(B, False)[0] for B in blocks]
+    try:
+        k = n_components
+        kc = min(n - 1, k + max(8, k // 4))
+        res = svd_snapshots(blocks, kc, oversample=oversample, flip_sign=False, comm=comm, kern=kern,
+                            eig_method=eig_method, deflate_mean=False)
+        kc = res.s.numel()
+        off, Ubl = 0, []
+        for B in blocks:
+            Ubl.append(res.Ut[:, off:off + B.shape[1]])
+            off += B.shape[1]
+        a = torch.zeros(kc, dtype=torch.float64, device=dev)
+        for U, mu in zip(Ubl, mus):
+            a += U.double() @ mu.double()
+        comm.allreduce_sum_(a)
+        ps = [mu.double() - U.double().T @ a for U, mu in zip(Ubl, mus)]
+        pn2 = torch.stack([(q * q).sum() for q in ps]).sum().reshape(1)
+        comm.allreduce_sum_(pn2)
+        pn = torch.sqrt(pn2[0])
+        rootn = math.sqrt(n)
+        K = torch.zeros((kc + 1, kc + 1), dtype=torch.float64, device=dev)
+        K[:kc, :kc] = torch.diag(res.s)
+        K[:kc, kc] = a * rootn
+        K[kc, kc] = pn * rootn
+        Uk, sk, Vkh = (t.contiguous() for t in torch.linalg.svd(K))
+        comm.broadcast_(Uk, sk, Vkh)
+        k = min(k, kc + 1)
+        s = sk[:k].contiguous()
+        Vext = torch.cat([res.Vh, torch.full((1, n), 1.0 / rootn, dtype=torch.float64, device=dev)], dim=0)
+        Vh = (Vkh[:k] @ Vext).contiguous()                       # rows of Vkh = right vectors of K
+        Rt = Uk[:, :k].T.contiguous().to(torch.float32)          # (k, kc + 1)
+        inv_pn = 1.0 / pn.clamp_min(1e-300)
+        Ub = []
+        for U, q in zip(Ubl, ps):
+            ext = torch.cat([U, (q * inv_pn).to(torch.float32)[None, :]], dim=0).contiguous()
+            Ub.append(kern.skinny(ext, Rt))                      # (k, m_b) = ([Uc, p^] Uk)^T
+    finally:
+        for B, mu in zip(blocks, mus):
+            B += mu                                              # un-centre: the caller's X is intact again
+    if flip_sign:
+        Ub, Vh = _sign_flip(Ub, Vh, comm, kern)
+    info = dict(res.info)
+    info.update(k=k, mean_deflated=True, l=res.info.get("l"))
+    if timings:
+        info["t_total"] = _sync_time(dev) - t0
+    return SvdResult(Ut=_assemble_rows(Ub, 1), s=s, Vh=Vh, info=info)
+
+
 def svd_snapshots(Xt, n_components: int, delay: int = 1, oversample: int | None = None,
                   refine: bool = True, flip_sign: bool = True, comm: Comm | None = None,
-                  kern=None, eig_method: str = "auto", timings: bool = False) -> SvdResult:
+                  kern=None, eig_method: str = "auto", timings: bool = False,
+                  deflate_mean: bool | None = None) -> SvdResult:
     """Rank-k SVD of the (delay-embedded) snapshot matrix by the Gram route.
 
     Xt: (n, m_local) fp32 device tensor -- or a list of such row blocks --
     already pre-processed (centred/scaled).  Returns local rows of U; s and V
     are replicated on every rank.
+
+    ``deflate_mean``: None = detect a dominant per-row time mean (un-centred data) on a sample
+    and, if there is one, take the rank-one-update route (_svd_snapshots_mean_deflated); True /
+    False force / forbid it.  Only without delay embedding.
     """
     kern = _kern(kern)
     comm = comm or Comm()
     info: dict = {}
     blocks = as_blocks(Xt)
     dev = blocks[0].device
+    if delay == 1 and refine and deflate_mean is not False and blocks[0].shape[0] > 2:
+        if deflate_mean is None:
+            deflate_mean = _time_mean_dominates(blocks, comm)
+        if deflate_mean:
+            return _svd_snapshots_mean_deflated(blocks, n_components, oversample, flip_sign, comm, kern,
+                                                eig_method, timings)
+    elif delay > 1 and deflate_mean is None and _time_mean_dominates(blocks, comm):
+        info["warning"] = ("the per-row time mean dominates the data (un-centred input) and delay embedding "
+                           "is on: the trailing singular values are limited by the conditioning of X^T X; "
+                           "centre the data (mean_center = True) for full accuracy")
     t0 = _sync_time(dev) if timings else 0.0
 
     G = _gram_blocks(blocks, kern, comm)

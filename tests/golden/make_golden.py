@@ -17,6 +17,8 @@ The reference package itself is not importable here (xarray/netCDF4/pyprojroot/d
 are not installed: ordinary ModuleNotFoundError), so SVD values are pinned on the
 third-party calls it makes, not on reference fixtures (it holds none: "parity
 unpinned" by reference tests).
+  * conditioning_2048x160.npz -- temperature-like data with and without its time mean (the
+    un-centred matrix has s_1 ~ 3e3 s_2): fp32 and fp64 `np.linalg.svd` of both, the inputs included.
 Vectors are stored sign-normalised (largest |entry| of each U column positive).
 """
 import os
@@ -79,6 +81,22 @@ def main():
             out.update({f"{tag}_s": sr, f"{tag}_U": Ur, f"{tag}_V": Vr,
                         f"{tag}_omega": omega.astype(np.float32)})
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    # 4. conditioning pair: the same anomalies with and without a large
+    # time-mean (temperature-like: 280 + O(1..10) anomalies).  Un-centred, s_1 is ~3e3 x s_2, which
+    # is what stresses a Gram-based SVD; centred, it is the well-conditioned problem.
+    m, n, k = 2048, 160, 12
+    anom = orc.lowrank_matrix(m, n, 40, seed=5) * 0.05
+    mean = 280.0 + 5.0 * np.random.RandomState(6).standard_normal((m, 1)).astype(np.float32)
+    raw = (anom + mean).astype(np.float32)
+    cen = (raw - raw.mean(axis=1, keepdims=True)).astype(np.float32)
+    out = dict(m=m, n=n, k=k)
+    for tag, X in (("raw", raw), ("cen", cen)):
+        U32, s32, V32 = orc.svd_standard(X, k)
+        U64, s64, V64 = orc.svd_standard(X.astype(np.float64), k)
+        U64, V64 = orc.svd_flip(U64, V64)
+        out.update({f"{tag}_X": X, f"{tag}_s32": s32, f"{tag}_s64": s64,
+                    f"{tag}_U64": U64.astype(np.float32), f"{tag}_V64": V64.astype(np.float32)})
+    np.savez_compressed(os.path.join(HERE, "conditioning_2048x160.npz"), **out)
     print("golden fixtures written to", HERE)
 
 

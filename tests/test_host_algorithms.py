@@ -170,3 +170,24 @@ def test_non_finite_input_raises_like_numpy():
     X[17, 3] = np.nan
     with pytest.raises(np.linalg.LinAlgError, match="did not converge"):
         dsvd.svd_snapshots(_xt(X), 5, kern=K)
+
+
+def test_uncentred_data_takes_the_mean_deflated_route():
+    """Temperature-like data with its time mean left in (s_1 ~ 3e4 s_2): the engine detects the
+    dominant mean, factors the centred matrix and applies the rank-one update; the result is
+    the SVD of the UN-centred matrix (golden: numpy fp64), and the caller's X is left untouched."""
+    g = np.load(os.path.join(GOLDEN, "conditioning_2048x160.npz"))
+    k = int(g["k"])
+    for tag, expect in (("raw", True), ("cen", False)):
+        X = g[f"{tag}_X"]
+        Xt = _xt(X)
+        keep = Xt.clone()
+        r = dsvd.svd_snapshots(Xt, k, kern=K)
+        assert bool(r.info.get("mean_deflated", False)) is expect
+        assert torch.allclose(Xt, keep, rtol=0, atol=1e-4)           # restored (fp32 add of the mean back)
+        assert np.abs(r.s.numpy() / g[f"{tag}_s64"] - 1).max() < 2e-6
+        assert col_cosines(r.Ut.numpy().T, g[f"{tag}_U64"]).min() > 1 - 1e-5
+        assert col_cosines(r.Vh.numpy().T, g[f"{tag}_V64"].T).min() > 1 - 1e-5
+        Urec = (r.Ut.numpy().T * r.s.numpy()) @ r.Vh.numpy()
+        top = (g[f"{tag}_U64"] * g[f"{tag}_s64"]) @ g[f"{tag}_V64"]
+        assert np.abs(Urec - top).max() < 1e-3 * np.abs(top).max()

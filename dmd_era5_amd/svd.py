@@ -460,6 +460,10 @@ def svd_snapshots(Xt, n_components: int, delay: int = 1, oversample: int | None 
     lam, V = top_eigh(G, l, method=eig_method, info=info, kern=kern)
     comm.broadcast_(lam, V)
     lam1 = lam[0].clamp_min(1e-300)
+    if float(lam[min(k, lam.numel()) - 1]) < 1e-8 * float(lam1) and "warning" not in info:
+        info["warning"] = ("s_k < 1e-4 s_1: the Gram matrix of fp32 products resolves eigenvalues down to "
+                           "~1e-9 lambda_1 only; the trailing singular values are less accurate than a "
+                           "LAPACK SVD of X would give")
     good = lam > lam1 * 1e-14
     s0 = torch.sqrt(torch.where(good, lam, torch.ones_like(lam)))
     inv_s0 = torch.where(good, 1.0 / s0, torch.zeros_like(s0))

@@ -426,3 +426,64 @@ def test_uncentred_temperature_like_data_matches_numpy_fp64():
         assert np.abs(s / g[f"{tag}_s64"] - 1).max() < 2e-6, tag
         assert col_cosines(U, g[f"{tag}_U64"]).min() > 1 - 1e-5
         assert col_cosines(V.T, g[f"{tag}_V64"].T).min() > 1 - 1e-5
+
+
+# ---------------------------------------------------------------- differential sweep
+def _fuzz_cases():
+    rs = np.random.RandomState(2024)
+    cases = []
+    for i in range(36):
+        m = int(rs.choice([3, 17, 64, 257, 1000, 4099, 20000]))
+        n = int(rs.choice([2, 5, 24, 96, 130, 300]))
+        k = int(rs.randint(1, min(m, n, 40) + 1))
+        kind = ["gauss", "lowrank", "deficient", "offset", "graded"][i % 5]
+        typ = "standard" if i % 3 else "randomized"
+        cases.append((i, m, n, k, kind, typ))
+    return cases
+
+
+@pytest.mark.parametrize("i,m,n,k,kind,typ", _fuzz_cases())
+def test_differential_sweep_against_numpy(i, m, n, k, kind, typ):
+    """Random shapes / spectra (tall, wide, tiny, rank-deficient, un-centred, graded), both SVD
+    types, against numpy fp64: singular values to 5e-5 s_1 (the resolution of a Gram matrix of
+    fp32 products is ~3e-5 s_1: sqrt of its 1e-9 lambda_1 floor -- reached only by the graded cases
+    whose s_k is below 1e-4 s_1, for which the engine also sets info["warning"]; randomized: where
+    sklearn itself is that good -- low-rank inputs), orthonormal factors, and the Eckart-Young property
+    ||X - U S V|| <= (1 + 1e-3) x the optimal rank-k error (+ 2e-4 ||X||, the same resolution
+    limit), which does not care
+    about degenerate singular values."""
+    from dmd_era5_amd.engine import svd_numpy
+
+    rs = np.random.RandomState(1000 + i)
+    if kind == "gauss":
+        X = rs.standard_normal((m, n))
+    elif kind == "lowrank":
+        r = max(1, min(m, n) // 3)
+        X = rs.standard_normal((m, r)) @ (rs.standard_normal((r, n)) * (0.8 ** np.arange(r))[:, None])
+        X += 1e-3 * rs.standard_normal((m, n))
+    elif kind == "deficient":
+        r = max(1, min(m, n, k) // 2)
+        X = rs.standard_normal((m, r)) @ rs.standard_normal((r, n))
+    elif kind == "offset":
+        X = 300.0 + rs.standard_normal((m, 1)) * 5 + rs.standard_normal((m, n))
+    else:
+        X = rs.standard_normal((m, n)) * (0.7 ** np.arange(n))
+    X = X.astype(np.float32)
+    opts = {"random_state": 0} if typ == "randomized" else {}
+    U, s, V = svd_numpy(X, typ, k, device="cuda:0", **opts)
+    X64 = X.astype(np.float64)
+    sref = np.linalg.svd(X64, compute_uv=False)
+    kk = min(k, m, n)
+    assert U.shape == (m, kk) and s.shape == (kk,) and V.shape == (kk, n)
+    assert np.all(np.diff(s) <= 1e-6 * s[0])
+    exact_type = typ == "standard" or kind in ("lowrank", "deficient")
+    if exact_type:
+        assert np.abs(s - sref[:kk]).max() <= 5e-5 * sref[0], (kind, typ, m, n, k)
+    live = s > 1e-4 * s[0]                                        # null directions carry no constraint
+    Ul, Vl = U[:, live].astype(np.float64), V[live].astype(np.float64)
+    assert np.abs(Ul.T @ Ul - np.eye(live.sum())).max() < 5e-4
+    assert np.abs(Vl @ Vl.T - np.eye(live.sum())).max() < 5e-4
+    err = np.linalg.norm(X64 - (U.astype(np.float64) * s) @ V.astype(np.float64))
+    opt = np.sqrt((sref[kk:] ** 2).sum())
+    if exact_type:
+        assert err <= (1 + 1e-3) * opt + 2e-4 * np.linalg.norm(X64), (kind, typ, m, n, k, err, opt)

@@ -337,76 +337,17 @@ def _sync_time(device) -> float:
 # "standard": method of snapshots
 # ---------------------------------------------------------------------------
 def _time_mean_dominates(blocks, comm: Comm) -> bool:
-    """Does the per-row time mean carry most of the energy of X (un-centred fields such as
-    temperature ~ 280 K + O(10) K anomalies)?  Estimated on up to 2048 rows of every block."""
+    """Does the per-row time mean carry > 99 % of the energy of X (un-centred fields such as
+    temperature ~ 280 K + O(10) K anomalies)?  Estimated on up to 2048 rows of every block.
+    (Below that ratio s_1 / s_2 stays in the hundreds, which the plain Gram route resolves; and
+    the deflation's Schur complement is exact only up to lambda_2 / lambda_1.)"""
     acc = torch.zeros(2, dtype=torch.float64, device=blocks[0].device)
     for B in blocks:
         var, mean = torch.var_mean(B[:, : min(2048, B.shape[1])].double(), dim=0, unbiased=False)
         acc[0] += (mean * mean).sum()
         acc[1] += var.sum()
     comm.allreduce_sum_(acc)
-    return bool(acc[0] > acc[1])
-
-
-def _svd_snapshots_mean_deflated(blocks, n_components, oversample, flip_sign, comm, kern, eig_method,
-                                 timings) -> SvdResult:
-    """SVD of X = Xc + mu 1^T through the SVD of the row-centred Xc and a rank-one update.
-
-    The Gram route squares the condition number: with a dominant time mean (s_1 ~ 1e4 s_2 for
-    un-centred temperature) the wanted trailing eigenvalues of X^T X drown in the rounding of its
-    fp32 products.  Xc is well conditioned, and since Xc 1 = 0 the ones vector is orthogonal to
-    every right singular vector of Xc:  X = [Uc, p^] K [Vc, 1/sqrt(n)]^T  with
-    K = [[Sc, a sqrt(n)], [0, |p| sqrt(n)]],  a = Uc^T mu,  p = mu - Uc a,  exactly for the kept
-    modes of Xc.  The blocks are centred in place (K5) and restored before returning."""
-    dev = blocks[0].device
-    n = blocks[0].shape[0]
-    t0 = _sync_time(dev) if timings else 0.0
-    mus = [kern.row_center_scale_(B, False)[0] for B in blocks]
-    try:
-        k = n_components
-        kc = min(n - 1, k + max(8, k // 4))
-        res = svd_snapshots(blocks, kc, oversample=oversample, flip_sign=False, comm=comm, kern=kern,
-                            eig_method=eig_method, deflate_mean=False)
-        kc = res.s.numel()
-        off, Ubl = 0, []
-        for B in blocks:
-            Ubl.append(res.Ut[:, off:off + B.shape[1]])
-            off += B.shape[1]
-        a = torch.zeros(kc, dtype=torch.float64, device=dev)
-        for U, mu in zip(Ubl, mus):
-            a += U.double() @ mu.double()
-        comm.allreduce_sum_(a)
-        ps = [mu.double() - U.double().T @ a for U, mu in zip(Ubl, mus)]
-        pn2 = torch.stack([(q * q).sum() for q in ps]).sum().reshape(1)
-        comm.allreduce_sum_(pn2)
-        pn = torch.sqrt(pn2[0])
-        rootn = math.sqrt(n)
-        K = torch.zeros((kc + 1, kc + 1), dtype=torch.float64, device=dev)
-        K[:kc, :kc] = torch.diag(res.s)
-        K[:kc, kc] = a * rootn
-        K[kc, kc] = pn * rootn
-        Uk, sk, Vkh = (t.contiguous() for t in torch.linalg.svd(K))
-        comm.broadcast_(Uk, sk, Vkh)
-        k = min(k, kc + 1)
-        s = sk[:k].contiguous()
-        Vext = torch.cat([res.Vh, torch.full((1, n), 1.0 / rootn, dtype=torch.float64, device=dev)], dim=0)
-        Vh = (Vkh[:k] @ Vext).contiguous()                       # rows of Vkh = right vectors of K
-        Rt = Uk[:, :k].T.contiguous().to(torch.float32)          # (k, kc + 1)
-        inv_pn = 1.0 / pn.clamp_min(1e-300)
-        Ub = []
-        for U, q in zip(Ubl, ps):
-            ext = torch.cat([U, (q * inv_pn).to(torch.float32)[None, :]], dim=0).contiguous()
-            Ub.append(kern.skinny(ext, Rt))                      # (k, m_b) = ([Uc, p^] Uk)^T
-    finally:
-        for B, mu in zip(blocks, mus):
-            B += mu                                              # un-centre: the caller's X is intact again
-    if flip_sign:
-        Ub, Vh = _sign_flip(Ub, Vh, comm, kern)
-    info = dict(res.info)
-    info.update(k=k, mean_deflated=True, l=res.info.get("l"))
-    if timings:
-        info["t_total"] = _sync_time(dev) - t0
-    return SvdResult(Ut=_assemble_rows(Ub, 1), s=s, Vh=Vh, info=info)
+    return bool(acc[0] > 100.0 * acc[1])
 
 
 def svd_snapshots(Xt, n_components: int, delay: int = 1, oversample: int | None = None,
@@ -420,81 +361,136 @@ def svd_snapshots(Xt, n_components: int, delay: int = 1, oversample: int | None 
     are replicated on every rank.
 
     ``deflate_mean``: None = detect a dominant per-row time mean (un-centred data) on a sample
-    and, if there is one, take the rank-one-update route (_svd_snapshots_mean_deflated); True /
-    False force / forbid it.  Only without delay embedding.
+    of rows; True / False force / forbid its exact deflation.  The Gram route squares the
+    condition number: with a dominant time mean (s_1 ~ 1e4 s_2 for un-centred temperature) the
+    wanted trailing eigenvalues of E^T E drown in the rounding of its fp32 products.  With
+    E = E(Xc) + mu~ 1^T (Xc row-centred, mu~ the time means repeated for every delay):
+        E^T E = A^T A + 1 w^T + w 1^T + |mu~|^2 1 1^T,     A = E(Xc),  w = A^T mu~,
+    and in the coordinates (q = 1/sqrt(nd), its complement P = I - q q^T) the mean terms vanish
+    from the complement:  P E^T E P = P A^T A P.  So the blocks are centred in place (K5), the
+    accurate small-scale Gram A^T A is computed as usual, the non-dominant eigenpairs come from
+    Gd = P A^T A P - z z^T / alpha  (alpha = q^T E^T E q, z = P E^T E q: the Schur complement of
+    the dominant direction, exact up to lambda / alpha ~ 1e-9), the (l x l) Rayleigh-Ritz in
+    span{q, V} restores the exact coupling, U' = E V S^-1 is formed as A V S^-1 + mu~ (1^T V) S^-1,
+    and the blocks are un-centred again before returning.
     """
     kern = _kern(kern)
     comm = comm or Comm()
     info: dict = {}
     blocks = as_blocks(Xt)
     dev = blocks[0].device
-    if delay == 1 and refine and deflate_mean is not False and blocks[0].shape[0] > 2:
-        if deflate_mean is None:
-            deflate_mean = _time_mean_dominates(blocks, comm)
-        if deflate_mean:
-            return _svd_snapshots_mean_deflated(blocks, n_components, oversample, flip_sign, comm, kern,
-                                                eig_method, timings)
-    elif delay > 1 and deflate_mean is None and _time_mean_dominates(blocks, comm):
-        info["warning"] = ("the per-row time mean dominates the data (un-centred input) and delay embedding "
-                           "is on: the trailing singular values are limited by the conditioning of X^T X; "
-                           "centre the data (mean_center = True) for full accuracy")
+    if deflate_mean is None:
+        deflate_mean = refine and blocks[0].shape[0] - delay + 1 > 2 and _time_mean_dominates(blocks, comm)
     t0 = _sync_time(dev) if timings else 0.0
+    mus = [kern.row_center_scale_(B, False)[0] for B in blocks] if deflate_mean else None
+    try:
+        G = _gram_blocks(blocks, kern, comm)
+        if not bool(torch.isfinite(torch.diagonal(G)).all()):
+            # NaN / Inf in X: what np.linalg.svd (the reference's call, era5_svd.py:251) reports
+            raise np.linalg.LinAlgError("SVD did not converge")
+        if mus is not None:
+            # w = Xc^T mu (n,), |mu|^2: one K3 pass with a single column
+            w = _gemm_tn_blocks([mu[None, :].contiguous() for mu in mus], blocks, kern, comm).reshape(-1)
+            musq = torch.stack([(mu.double() ** 2).sum() for mu in mus]).sum().reshape(1)
+            comm.allreduce_sum_(musq)
+        if delay > 1:
+            G = kern.delay_shift_sum(G, delay)
+            if mus is not None:   # w_E[t] = sum_k w[t + k]
+                ndw = w.numel() - delay + 1
+                w = torch.stack([w[kd:kd + ndw] for kd in range(delay)]).sum(dim=0)
+        nd = G.shape[0]
+        t1 = _sync_time(dev) if timings else 0.0
 
-    G = _gram_blocks(blocks, kern, comm)
-    if not bool(torch.isfinite(torch.diagonal(G)).all()):
-        # NaN / Inf in X: what np.linalg.svd (the reference's call, era5_svd.py:251) reports
-        raise np.linalg.LinAlgError("SVD did not converge")
-    if delay > 1:
-        G = kern.delay_shift_sum(G, delay)
-    nd = G.shape[0]
-    t1 = _sync_time(dev) if timings else 0.0
+        Mg = sum(B.shape[1] for B in blocks) * delay
+        if comm.world_size > 1:
+            tot = torch.tensor([Mg], dtype=torch.int64, device=dev)
+            comm.allreduce_sum_(tot)
+            Mg = int(tot.item())
+        k = min(n_components, nd, Mg)  # np.linalg.svd(full_matrices=False)[:k]
+        p = oversample if oversample is not None else max(8, k // 4)
+        l = min(nd, k + p) if refine else k
+        if mus is None:
+            lam, V = top_eigh(G, l, method=eig_method, info=info, kern=kern)
+        else:
+            rootn = math.sqrt(nd)
+            q = torch.full((nd,), 1.0 / rootn, dtype=torch.float64, device=dev)
+            h = G @ q
+            qh = torch.dot(q, h)
+            alpha = qh + 2.0 * rootn * torch.dot(w, q) + delay * musq[0] * nd
+            zf = h + rootn * w
+            z = zf - q * torch.dot(q, zf)
+            Gd = G - torch.outer(q, h) - torch.outer(h, q) + qh * torch.outer(q, q) - torch.outer(z, z) / alpha
+            Gd = 0.5 * (Gd + Gd.T)
+            lam_d, Vd = top_eigh(Gd, max(1, l - 1), method=eig_method, info=info, kern=kern)
+            # Basis of the complement: z itself (G q = alpha q + z: with it the dominant pair is
+            # exact up to lambda_2 / alpha, whatever part of z lies outside the kept modes) and the
+            # leading eigenvectors of Gd, projected off q (a rank-deficient Gd returns arbitrary
+            # null vectors, q among them); the projected matrix comes from products, not from lam_d.
+            Bs = torch.cat([z[:, None] / torch.linalg.vector_norm(z).clamp_min(1e-300), Vd], dim=1)
+            Bs = _orth(Bs - torch.outer(q, q @ Bs))
+            c = Bs.T @ z
+            T11 = Bs.T @ (Gd @ Bs) + torch.outer(c, c) / alpha
+            T = torch.zeros((Bs.shape[1] + 1,) * 2, dtype=torch.float64, device=dev)
+            T[0, 0] = alpha
+            T[0, 1:] = c
+            T[1:, 0] = c
+            T[1:, 1:] = 0.5 * (T11 + T11.T)
+            Vd = Bs
+            lam, Z0 = _eigh_desc(T, kern)
+            l = min(l, lam.numel())
+            lam, Z0 = lam[:l].contiguous(), Z0[:, :l]
+            V = torch.cat([q[:, None], Vd], dim=1) @ Z0
+            info["mean_deflated"] = True
+        comm.broadcast_(lam, V)
+        lam1 = lam[0].clamp_min(1e-300)
+        ref = lam[1] if (mus is not None and lam.numel() > 1) else lam1   # the deflated scale
+        if float(lam[min(k, lam.numel()) - 1]) < 1e-8 * float(ref):
+            info["warning"] = ("s_k < 1e-4 s_1: the Gram matrix of fp32 products resolves eigenvalues down to "
+                               "~1e-9 lambda_1 only; the trailing singular values are less accurate than a "
+                               "LAPACK SVD of X would give")
+        good = lam > lam1 * 1e-14
+        if mus is not None:
+            # resolvable: above the rounding of the deflated Gram (scale lam_d[0]) and above the
+            # rounding the dominant entry alpha leaves in the small Rayleigh-Ritz problem
+            good = lam > torch.maximum(lam_d[0].abs() * 1e-13, lam1 * 1e-15)
+        s0 = torch.sqrt(torch.where(good, lam, torch.ones_like(lam)))
+        inv_s0 = torch.where(good, 1.0 / s0, torch.zeros_like(s0))
+        s0 = torch.where(good, s0, torch.zeros_like(s0))
+        t2 = _sync_time(dev) if timings else 0.0
 
-    Mg = sum(B.shape[1] for B in blocks) * delay
-    if comm.world_size > 1:
-        tot = torch.tensor([Mg], dtype=torch.int64, device=dev)
-        comm.allreduce_sum_(tot)
-        Mg = int(tot.item())
-    k = min(n_components, nd, Mg)  # np.linalg.svd(full_matrices=False)[:k]
-    p = oversample if oversample is not None else max(8, k // 4)
-    l = min(nd, k + p) if refine else k
-    lam, V = top_eigh(G, l, method=eig_method, info=info, kern=kern)
-    comm.broadcast_(lam, V)
-    lam1 = lam[0].clamp_min(1e-300)
-    if float(lam[min(k, lam.numel()) - 1]) < 1e-8 * float(lam1) and "warning" not in info:
-        info["warning"] = ("s_k < 1e-4 s_1: the Gram matrix of fp32 products resolves eigenvalues down to "
-                           "~1e-9 lambda_1 only; the trailing singular values are less accurate than a "
-                           "LAPACK SVD of X would give")
-    good = lam > lam1 * 1e-14
-    s0 = torch.sqrt(torch.where(good, lam, torch.ones_like(lam)))
-    inv_s0 = torch.where(good, 1.0 / s0, torch.zeros_like(s0))
-    s0 = torch.where(good, s0, torch.zeros_like(s0))
-    t2 = _sync_time(dev) if timings else 0.0
+        Wt = (V * inv_s0).T.contiguous().to(torch.float32)           # (l, nd)
+        Up = [kern.skinny(embed_view(B, delay), Wt) for B in blocks]  # (l, d*mb): U' = X V S^-1
+        if mus is not None:   # + mu~ (1^T V) S^-1: the part of E the centred blocks no longer hold
+            cvec = (V.sum(dim=0) * inv_s0).to(torch.float32)
+            for U, mu in zip(Up, mus):
+                U.addmm_(cvec[:, None], mu.repeat(delay)[None, :])
+        t3 = _sync_time(dev) if timings else 0.0
 
-    Wt = (V * inv_s0).T.contiguous().to(torch.float32)           # (l, nd)
-    Up = [kern.skinny(embed_view(B, delay), Wt) for B in blocks]  # (l, d*mb): U' = X V S^-1
-    t3 = _sync_time(dev) if timings else 0.0
-
-    if refine:
-        # Rayleigh-Ritz in span(V): (XV)^T (XV) = S (U'^T U') S, graded by S so the
-        # small singular values keep their relative accuracy.
-        Mm = _gram_blocks(Up, kern, comm)                         # (l, l) fp64
-        T = s0[:, None] * Mm * s0[None, :]
-        T = 0.5 * (T + T.T)
-        mu, Z = _eigh_desc(T, kern)
-        mu = mu[:k].contiguous()
-        Z = Z[:, :k].contiguous()
-        comm.broadcast_(mu, Z)
-        s = torch.sqrt(mu.clamp_min(0.0))
-        ok = s > s0[0] * 1e-7
-        inv_s = torch.where(ok, 1.0 / torch.where(ok, s, torch.ones_like(s)), torch.zeros_like(s))
-        Rm = (s0[:, None] * Z) * inv_s[None, :]                   # (l, k): U = U' R
-        Rt = Rm.T.contiguous().to(torch.float32)
-        Ub = [kern.skinny(U, Rt) for U in Up]                     # (k, d*mb)
-        Vh = (V @ Z).T.contiguous()
-    else:
-        s = s0[:k]
-        Ub = [U[:k] for U in Up]
-        Vh = V[:, :k].T.contiguous()
+        if refine:
+            # Rayleigh-Ritz in span(V): (XV)^T (XV) = S (U'^T U') S, graded by S so the
+            # small singular values keep their relative accuracy.
+            Mm = _gram_blocks(Up, kern, comm)                         # (l, l) fp64
+            T = s0[:, None] * Mm * s0[None, :]
+            T = 0.5 * (T + T.T)
+            mu_, Z = _eigh_desc(T, kern)
+            mu_ = mu_[:k].contiguous()
+            Z = Z[:, :k].contiguous()
+            comm.broadcast_(mu_, Z)
+            s = torch.sqrt(mu_.clamp_min(0.0))
+            ok = s > s0[0] * 1e-7 if mus is None else s > 0
+            inv_s = torch.where(ok, 1.0 / torch.where(ok, s, torch.ones_like(s)), torch.zeros_like(s))
+            Rm = (s0[:, None] * Z) * inv_s[None, :]                   # (l, k): U = U' R
+            Rt = Rm.T.contiguous().to(torch.float32)
+            Ub = [kern.skinny(U, Rt) for U in Up]                     # (k, d*mb)
+            Vh = (V @ Z).T.contiguous()
+        else:
+            s = s0[:k]
+            Ub = [U[:k] for U in Up]
+            Vh = V[:, :k].T.contiguous()
+    finally:
+        if mus is not None:
+            for B, mu in zip(blocks, mus):
+                B += mu                                              # un-centre: the caller's X is intact again
     if flip_sign:
         Ub, Vh = _sign_flip(Ub, Vh, comm, kern)
     Ut = _assemble_rows(Ub, delay)

@@ -415,7 +415,7 @@ def test_gemm_tn_blocks_equals_sum_of_block_products(K, sizes, na, nb):
 def test_uncentred_temperature_like_data_matches_numpy_fp64():
     """mean_center = False on temperature-like data (s_1 ~ 3e4 s_2): the plain Gram route loses
     the trailing singular values in the rounding of the fp32 products (76 % error on s_2 measured);
-    the engine detects the dominant time mean and takes the rank-one-update route.  Bound: 2e-6
+    the engine detects the dominant time mean and deflates it exactly.  Bound: 2e-6
     relative on every singular value against numpy fp64 (numpy's own fp32 LAPACK: 6e-8)."""
     from dmd_era5_amd.engine import svd_numpy
 

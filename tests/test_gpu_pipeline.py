@@ -160,3 +160,32 @@ def test_main_direct_pinned_ingest_path(svd_base_config, project_root, monkeypat
     assert np.allclose(res["X"].values, X, rtol=0, atol=2e-4)
     _, so, _ = orc.svd_standard(X.astype(np.float64), 4)
     assert np.allclose(res["s"].values, so, rtol=2e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d", [1, 2])
+def test_main_uncentred_temperature_matches_oracle(svd_base_config, project_root, d):
+    """mean_center = False on a temperature field (values ~ 280 K): the pipeline must still return
+    the SVD of the UN-centred matrix; it goes through the mean-deflated route (the plain Gram
+    route loses the trailing singular values there).  Truth: oracle preprocessing + numpy fp64."""
+    from dmd_era5_amd.era5_svd import main
+
+    cfg = dict(svd_base_config, start_datetime="2019-01-01T00", end_datetime="2019-01-04T00",
+               variables="temperature", levels="1000", svd_type="standard", mean_center=False, scale=False,
+               delay_embedding=d, n_components=5, save_data_matrix=True)
+    p, ds = _write_slice(cfg, seed=11, dtype=np.float32)
+    res, _, _ = main(cfg, write_to_netcdf=False)
+    X, _, _ = orc.preprocess({k: ds[k].values for k in p["variables"]}, False, False, d)
+    assert np.allclose(res["X"].values, X, rtol=0, atol=1e-3)               # restored after the in-place centring
+    Uo, so, Vo = orc.svd_standard(X.astype(np.float64), 5)
+    assert so[0] > 100 * so[1]                                              # the mean mode dominates
+    # fp32 data with s_1 / s_i ~ 220: numpy's own fp32 LAPACK answer is good to ~eps32 s_1 / s_i = 1e-5
+    assert np.allclose(res["s"].values, so, rtol=1e-5)
+    # the noise singular values cluster (mock data are white noise), so the rank-5 truncation is
+    # compared through its error, which must be the Eckart-Young optimum, not vector by vector
+    X64 = X.astype(np.float64)
+    rec = (res["U"].values.astype(np.float64) * res["s"].values) @ res["V"].values
+    sall = np.linalg.svd(X64, compute_uv=False)
+    assert np.linalg.norm(X64 - rec) <= (1 + 1e-4) * np.sqrt((sall[5:] ** 2).sum())
+    U = res["U"].values.astype(np.float64)
+    assert np.abs(U.T @ U - np.eye(5)).max() < 1e-4

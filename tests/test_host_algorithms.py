@@ -174,8 +174,8 @@ def test_non_finite_input_raises_like_numpy():
 
 def test_uncentred_data_takes_the_mean_deflated_route():
     """Temperature-like data with its time mean left in (s_1 ~ 3e4 s_2): the engine detects the
-    dominant mean, factors the centred matrix and applies the rank-one update; the result is
-    the SVD of the UN-centred matrix (golden: numpy fp64), and the caller's X is left untouched."""
+    dominant mean and deflates it exactly (centred Gram + Schur complement of the mean
+    direction); the result is the SVD of the UN-centred matrix (golden: numpy fp64), and the caller's X is left untouched."""
     g = np.load(os.path.join(GOLDEN, "conditioning_2048x160.npz"))
     k = int(g["k"])
     for tag, expect in (("raw", True), ("cen", False)):
@@ -191,3 +191,20 @@ def test_uncentred_data_takes_the_mean_deflated_route():
         Urec = (r.Ut.numpy().T * r.s.numpy()) @ r.Vh.numpy()
         top = (g[f"{tag}_U64"] * g[f"{tag}_s64"]) @ g[f"{tag}_V64"]
         assert np.abs(Urec - top).max() < 1e-3 * np.abs(top).max()
+
+
+@pytest.mark.parametrize("d", [2, 3])
+def test_uncentred_data_with_delay_embedding(d):
+    """Mean deflation under delay embedding: the embedding of un-centred data is the embedding of
+    the centred data plus (tiled mean) 1^T; the ones vector is no longer in the null space of the
+    centred Gram (window sums of a centred series are small, not zero), which the projected form
+    P A^T A P handles exactly.  Truth: numpy fp64 SVD of the materialised embedding."""
+    g = np.load(os.path.join(GOLDEN, "conditioning_2048x160.npz"))
+    X = g["raw_X"][:600]
+    Xe = orc.delay_embed(X, d)
+    Ue, se, Ve = orc.svd_standard(Xe.astype(np.float64), 8)
+    r = dsvd.svd_snapshots(_xt(X), 8, delay=d, kern=K)
+    assert r.info.get("mean_deflated")
+    assert np.abs(r.s.numpy() / se - 1).max() < 2e-6
+    assert col_cosines(r.Ut.numpy().T, Ue).min() > 1 - 1e-5
+    assert col_cosines(r.Vh.numpy().T, Ve.T).min() > 1 - 1e-5

@@ -444,11 +444,28 @@ def svd_snapshots(Xt, n_components: int, delay: int = 1, oversample: int | None 
         comm.broadcast_(lam, V)
         lam1 = lam[0].clamp_min(1e-300)
         ref = lam[1] if (mus is not None and lam.numel() > 1) else lam1   # the deflated scale
-        if float(lam[min(k, lam.numel()) - 1]) < 1e-8 * float(ref):
-            info["warning"] = ("s_k < 1e-4 s_1: the Gram matrix of fp32 products resolves eigenvalues down to "
+        steep = float(lam[min(k, lam.numel()) - 1]) < 1e-7 * float(ref)
+        polish = steep and refine and mus is None
+        if polish:
+            # Steep spectrum (s_k < 3e-4 s_1): G (sums of fp32 products) resolves eigenvalues down
+            # to ~1e-9 lambda_1 only, so the trailing wanted directions are poorly determined by
+            # it.  One subspace iteration on X itself, V <- orth(E^T (E V)) (a K2 and a K3 pass),
+            # fixes them up to the rounding of those products (~1e-7 s_1 / s_j relative); the
+            # Rayleigh-Ritz below then runs on the un-normalised E V.
+            Eb = [embed_view(B, delay) for B in blocks]
+            Yb = [kern.skinny(E, V.T.contiguous().to(torch.float32)) for E in Eb]
+            Zt = _gemm_tn_blocks(Eb, Yb, kern, comm)                  # (l, nd) = (E^T E V)^T
+            V = _orth(Zt.T.contiguous())
+            comm.broadcast_(V)
+            lam = torch.ones_like(lam)                                # no S^-1 scaling of E V below
+            info["polished"] = True
+        elif steep:
+            info["warning"] = ("s_k < 3e-4 s_1: the Gram matrix of fp32 products resolves eigenvalues down to "
                                "~1e-9 lambda_1 only; the trailing singular values are less accurate than a "
                                "LAPACK SVD of X would give")
         good = lam > lam1 * 1e-14
+        if polish:
+            good = torch.ones_like(lam, dtype=torch.bool)
         if mus is not None:
             # resolvable: above the rounding of the deflated Gram (scale lam_d[0]) and above the
             # rounding the dominant entry alpha leaves in the small Rayleigh-Ritz problem
@@ -477,7 +494,7 @@ def svd_snapshots(Xt, n_components: int, delay: int = 1, oversample: int | None 
             Z = Z[:, :k].contiguous()
             comm.broadcast_(mu_, Z)
             s = torch.sqrt(mu_.clamp_min(0.0))
-            ok = s > s0[0] * 1e-7 if mus is None else s > 0
+            ok = s > s0[0] * 1e-7 if (mus is None and not polish) else s > s[0] * 1e-7
             inv_s = torch.where(ok, 1.0 / torch.where(ok, s, torch.ones_like(s)), torch.zeros_like(s))
             Rm = (s0[:, None] * Z) * inv_s[None, :]                   # (l, k): U = U' R
             Rt = Rm.T.contiguous().to(torch.float32)

@@ -31,7 +31,7 @@ for i in range(N):
     err = np.linalg.norm(X64 - (U.astype(np.float64) * s) @ V.astype(np.float64)); opt = np.sqrt((sref[kk:] ** 2).sum())
     live = s > 1e-4 * s[0]; Ul = U[:, live].astype(np.float64)
     orth = np.abs(Ul.T @ Ul - np.eye(live.sum())).max() if live.any() else 0
-    flag = (exact and (ds > 5e-5 or err > 1.001 * opt + 2e-4 * np.linalg.norm(X64))) or orth > 5e-4 or not np.all(np.isfinite(s))
+    flag = (exact and (ds > 2e-5 or err > 1.001 * opt + 5e-5 * np.linalg.norm(X64))) or orth > 5e-4 or not np.all(np.isfinite(s))
     if flag:
         bad += 1
         print("BAD", i, m, n, k, kind, typ, "ds/s1 %.2e err %.3e opt %.3e orth %.1e" % (ds, err, opt, orth), flush=True)

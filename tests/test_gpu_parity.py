@@ -445,12 +445,11 @@ def _fuzz_cases():
 @pytest.mark.parametrize("i,m,n,k,kind,typ", _fuzz_cases())
 def test_differential_sweep_against_numpy(i, m, n, k, kind, typ):
     """Random shapes / spectra (tall, wide, tiny, rank-deficient, un-centred, graded), both SVD
-    types, against numpy fp64: singular values to 5e-5 s_1 (the resolution of a Gram matrix of
-    fp32 products is ~3e-5 s_1: sqrt of its 1e-9 lambda_1 floor -- reached only by the graded cases
-    whose s_k is below 1e-4 s_1, for which the engine also sets info["warning"]; randomized: where
+    types, against numpy fp64: singular values to 2e-5 s_1 (a Gram matrix of fp32 products alone
+    resolves ~3e-5 s_1, sqrt of its 1e-9 lambda_1 floor; the graded cases whose s_k is below
+    3e-4 s_1 get the extra subspace iteration on X itself and land at ~2e-7 s_1; randomized: where
     sklearn itself is that good -- low-rank inputs), orthonormal factors, and the Eckart-Young property
-    ||X - U S V|| <= (1 + 1e-3) x the optimal rank-k error (+ 2e-4 ||X||, the same resolution
-    limit), which does not care
+    ||X - U S V|| <= (1 + 1e-3) x the optimal rank-k error (+ 5e-5 ||X||), which does not care
     about degenerate singular values."""
     from dmd_era5_amd.engine import svd_numpy
 
@@ -478,7 +477,7 @@ def test_differential_sweep_against_numpy(i, m, n, k, kind, typ):
     assert np.all(np.diff(s) <= 1e-6 * s[0])
     exact_type = typ == "standard" or kind in ("lowrank", "deficient")
     if exact_type:
-        assert np.abs(s - sref[:kk]).max() <= 5e-5 * sref[0], (kind, typ, m, n, k)
+        assert np.abs(s - sref[:kk]).max() <= 2e-5 * sref[0], (kind, typ, m, n, k)
     live = s > 1e-4 * s[0]                                        # null directions carry no constraint
     Ul, Vl = U[:, live].astype(np.float64), V[live].astype(np.float64)
     assert np.abs(Ul.T @ Ul - np.eye(live.sum())).max() < 5e-4
@@ -486,4 +485,4 @@ def test_differential_sweep_against_numpy(i, m, n, k, kind, typ):
     err = np.linalg.norm(X64 - (U.astype(np.float64) * s) @ V.astype(np.float64))
     opt = np.sqrt((sref[kk:] ** 2).sum())
     if exact_type:
-        assert err <= (1 + 1e-3) * opt + 2e-4 * np.linalg.norm(X64), (kind, typ, m, n, k, err, opt)
+        assert err <= (1 + 1e-3) * opt + 5e-5 * np.linalg.norm(X64), (kind, typ, m, n, k, err, opt)

@@ -445,7 +445,7 @@ def svd_snapshots(Xt, n_components: int, delay: int = 1, oversample: int | None 
         lam1 = lam[0].clamp_min(1e-300)
         ref = lam[1] if (mus is not None and lam.numel() > 1) else lam1   # the deflated scale
         steep = float(lam[min(k, lam.numel()) - 1]) < 1e-7 * float(ref)
-        polish = steep and refine and mus is None
+        polish = steep and refine
         if polish:
             # Steep spectrum (s_k < 3e-4 s_1): G (sums of fp32 products) resolves eigenvalues down
             # to ~1e-9 lambda_1 only, so the trailing wanted directions are poorly determined by
@@ -454,19 +454,30 @@ def svd_snapshots(Xt, n_components: int, delay: int = 1, oversample: int | None 
             # Rayleigh-Ritz below then runs on the un-normalised E V.
             Eb = [embed_view(B, delay) for B in blocks]
             Yb = [kern.skinny(E, V.T.contiguous().to(torch.float32)) for E in Eb]
-            Zt = _gemm_tn_blocks(Eb, Yb, kern, comm)                  # (l, nd) = (E^T E V)^T
-            V = _orth(Zt.T.contiguous())
+            if mus is not None:   # E = A + mu~ 1^T on the centred blocks: Y += mu~ (1^T V)
+                ones_v = V.sum(dim=0).to(torch.float32)
+                for Y, mu in zip(Yb, mus):
+                    Y.addmm_(ones_v[:, None], mu.repeat(delay)[None, :])
+            Zt = _gemm_tn_blocks(Eb, Yb, kern, comm)                  # (l, nd) = (A^T Y)^T
+            if mus is not None:   # ... and E^T Y = A^T Y + 1 (mu~^T Y)
+                my = torch.zeros(Zt.shape[0], dtype=torch.float64, device=dev)
+                for Y, mu in zip(Yb, mus):
+                    my += Y.double() @ mu.double().repeat(delay)
+                comm.allreduce_sum_(my)
+                Zt = Zt + my[:, None]
+            Zn = Zt / torch.linalg.vector_norm(Zt, dim=1, keepdim=True).clamp_min(1e-300)
+            V = _orth(Zn.T.contiguous())   # (columns span ~s_j^2: normalised first, CholeskyQR is not scale invariant)
             comm.broadcast_(V)
             lam = torch.ones_like(lam)                                # no S^-1 scaling of E V below
             info["polished"] = True
         elif steep:
-            info["warning"] = ("s_k < 3e-4 s_1: the Gram matrix of fp32 products resolves eigenvalues down to "
-                               "~1e-9 lambda_1 only; the trailing singular values are less accurate than a "
-                               "LAPACK SVD of X would give")
+            info["warning"] = ("s_k < 3e-4 s_1 and refine=False: the Gram matrix of fp32 products resolves "
+                               "eigenvalues down to ~1e-9 lambda_1 only")
         good = lam > lam1 * 1e-14
         if polish:
             good = torch.ones_like(lam, dtype=torch.bool)
-        if mus is not None:
+            ref = lam1 = lam[0]
+        if mus is not None and not polish:
             # resolvable: above the rounding of the deflated Gram (scale lam_d[0]) and above the
             # rounding the dominant entry alpha leaves in the small Rayleigh-Ritz problem
             good = lam > torch.maximum(lam_d[0].abs() * 1e-13, lam1 * 1e-15)

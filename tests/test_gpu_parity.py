@@ -486,3 +486,22 @@ def test_differential_sweep_against_numpy(i, m, n, k, kind, typ):
     opt = np.sqrt((sref[kk:] ** 2).sum())
     if exact_type:
         assert err <= (1 + 1e-3) * opt + 5e-5 * np.linalg.norm(X64), (kind, typ, m, n, k, err, opt)
+
+
+def test_steep_spectrum_gets_the_polish_step(K):
+    """s_k / s_1 = 5e-7 (columns scaled by 0.7^j): below what the Gram matrix of fp32 products
+    resolves (~3e-5 s_1).  The engine must notice (lambda_k < 1e-7 lambda_1), run the extra
+    subspace iteration on X and reach 1e-6 s_1 (measured 1.8e-7; numpy fp32 LAPACK 3e-8)."""
+    from dmd_era5_amd import svd as dsvd
+
+    rs = np.random.RandomState(1029)
+    X = (rs.standard_normal((5000, 120)) * (0.7 ** np.arange(120))).astype(np.float32)
+    k = 40
+    sref = np.linalg.svd(X.astype(np.float64), compute_uv=False)
+    r = dsvd.svd_snapshots(_dev(X.T), k, kern=K)
+    assert r.info.get("polished") and "warning" not in r.info
+    s = r.s.cpu().numpy()
+    assert np.abs(s - sref[:k]).max() <= 1e-6 * sref[0]
+    assert (np.abs(s - sref[:k]) / sref[:k]).max() <= 1e-3          # even the smallest, 6e-7 s_1
+    plain = dsvd.svd_snapshots(_dev(X.T), 10, kern=K)                # s_10 / s_1 = 0.04: no polish
+    assert not plain.info.get("polished")

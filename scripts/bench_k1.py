@@ -9,6 +9,7 @@ ap.add_argument("--n", type=int, default=8760)
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--blocks", type=int, default=1)
 ap.add_argument("--batched", action="store_true", help="one launch for all blocks (dmdx_syrk_blocks_f32)")
+ap.add_argument("--group", type=int, default=0, help="with --batched: blocks per launch (0 = all)")
 a = ap.parse_args()
 K = default_kernels()
 g = torch.Generator(device="cuda").manual_seed(1)
@@ -16,7 +17,12 @@ mb = a.m // a.blocks
 Xb = [torch.randn((a.n, mb), generator=g, device="cuda", dtype=torch.float32) for _ in range(a.blocks)]
 def gram():
     if a.batched:
-        return K.syrk_blocks(Xb)
+        if a.group <= 0:
+            return K.syrk_blocks(Xb)
+        G = K.syrk_blocks(Xb[:a.group])
+        for i in range(a.group, len(Xb), a.group):
+            K.syrk_blocks(Xb[i:i + a.group], out=G)
+        return G
     G = K.syrk(Xb[0])
     for B in Xb[1:]: K.syrk(B, out=G)
     return G

@@ -556,8 +556,15 @@ def _cholqr(Yb, comm: Comm, kern, passes: int = 1):
         bad = int(err) != 0 or not bool(torch.isfinite(diag).all()) or \
             float(diag.min()) < 1e-4 * float(diag.max())
         if bad:
-            shift = 1e-6 * torch.diagonal(G).sum()
-            L = torch.linalg.cholesky(G + shift * eye)
+            # (the Gram of fp32 products can be indefinite by more than 1e-6 of its trace --
+            # identical values accumulate their rounding coherently -- so the shift escalates)
+            tr = torch.diagonal(G).sum()
+            for rel in (1e-6, 3e-5, 1e-3, 3e-2):
+                L, err = torch.linalg.cholesky_ex(G + (rel * tr) * eye)
+                if int(err) == 0 and bool(torch.isfinite(torch.diagonal(L)).all()):
+                    break
+            else:
+                raise np.linalg.LinAlgError("CholeskyQR: the Gram matrix of the range-finder block is not finite")
             todo += 1
         Rinv = torch.linalg.solve_triangular(L.T, eye, upper=True)  # R = L^T
         Rt = comm.broadcast_(Rinv.T.contiguous().to(torch.float32))

@@ -6,7 +6,8 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 rs0 = np.random.RandomState(77)
 bad = 0
 for i in range(N):
-    m = int(rs0.choice([3, 9, 17, 64, 257, 1000, 4099, 20000, 70000])); n = int(rs0.choice([2, 3, 5, 24, 96, 130, 300, 700]))
+    m = int(rs0.choice([3, 9, 17, 64, 257, 1000, 4099, 20000, 70000, 300001, 524288])); n = int(rs0.choice([2, 3, 5, 24, 96, 130, 300, 700]))
+    if m > 100000 and n > 300: n = 300
     k = int(rs0.randint(1, min(m, n, 60) + 1)); kind = ["gauss", "lowrank", "deficient", "offset", "graded", "offsetlow", "const"][i % 7]
     typ = "standard" if i % 3 else "randomized"
     rs = np.random.RandomState(5000 + i)

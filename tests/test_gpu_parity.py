@@ -505,3 +505,18 @@ def test_steep_spectrum_gets_the_polish_step(K):
     assert (np.abs(s - sref[:k]) / sref[:k]).max() <= 1e-3          # even the smallest, 6e-7 s_1
     plain = dsvd.svd_snapshots(_dev(X.T), 10, kern=K)                # s_10 / s_1 = 0.04: no polish
     assert not plain.info.get("polished")
+
+
+@pytest.mark.parametrize("typ", ["standard", "randomized"])
+def test_constant_matrix(typ):
+    """A constant matrix (exactly rank 1, identical addends in every fp32 chain: the rounding of
+    the Gram accumulates coherently, ~2e-6 of its trace, and makes it indefinite).  Both SVD
+    types must return s_1 = c sqrt(m n) and (numerically) zero for the rest, like numpy/sklearn."""
+    from dmd_era5_amd.engine import svd_numpy
+
+    m, n, k = 20000, 300, 6
+    X = np.full((m, n), 3.5, dtype=np.float32)
+    U, s, V = svd_numpy(X, typ, k, device="cuda:0", **({"random_state": 0} if typ == "randomized" else {}))
+    assert abs(s[0] / (3.5 * np.sqrt(m * n)) - 1) < 1e-6
+    assert np.all(s[1:] < 1e-4 * s[0])
+    assert np.abs(np.abs(U[:, 0]) - 1 / np.sqrt(m)).max() < 1e-6 and np.abs(np.abs(V[0]) - 1 / np.sqrt(n)).max() < 1e-6

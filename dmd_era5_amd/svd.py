@@ -336,6 +336,38 @@ def _sync_time(device) -> float:
 # ---------------------------------------------------------------------------
 # "standard": method of snapshots
 # ---------------------------------------------------------------------------
+def _magnitude_guard(fn):
+    """Entry-point decorator: data far outside the fp32 comfort zone (|x| ~ 1e20: the squares
+    overflow; ~1e-20: they underflow) are scaled in place by a power of two (exact), factored,
+    and scaled back; s is scaled accordingly.  LAPACK's gesdd does the same (xLASCL).  The
+    magnitude is read from up to 2048 rows of every block."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(Xt, *args, **kwargs):
+        blocks = as_blocks(Xt)
+        comm = kwargs.get("comm") or Comm()
+        amax = torch.stack([B[:, : min(2048, B.shape[1])].abs().max() for B in blocks]).max().double().reshape(1)
+        if comm.world_size > 1:
+            amax = torch.stack(comm.allgather(amax)).max().reshape(1)
+        a = float(amax[0])
+        if not (math.isfinite(a) and a > 0.0) or 2.0 ** -40 <= a <= 2.0 ** 40:
+            return fn(blocks, *args, **kwargs)
+        c = 2.0 ** (-round(math.log2(a)))
+        for B in blocks:
+            B *= c
+        try:
+            res = fn(blocks, *args, **kwargs)
+        finally:
+            for B in blocks:
+                B *= 1.0 / c
+        res.s = res.s / c
+        res.info["rescaled_by"] = c
+        return res
+
+    return wrapper
+
+
 def _time_mean_dominates(blocks, comm: Comm) -> bool:
     """Does the per-row time mean carry > 99 % of the energy of X (un-centred fields such as
     temperature ~ 280 K + O(10) K anomalies)?  Estimated on up to 2048 rows of every block.
@@ -350,6 +382,7 @@ def _time_mean_dominates(blocks, comm: Comm) -> bool:
     return bool(acc[0] > 100.0 * acc[1])
 
 
+@_magnitude_guard
 def svd_snapshots(Xt, n_components: int, delay: int = 1, oversample: int | None = None,
                   refine: bool = True, flip_sign: bool = True, comm: Comm | None = None,
                   kern=None, eig_method: str = "auto", timings: bool = False,
@@ -579,6 +612,7 @@ def resolve_n_iter(n_components: int, m: int, n: int, n_iter="auto") -> int:
     return int(n_iter)
 
 
+@_magnitude_guard
 def svd_randomized(Xt, n_components: int, delay: int = 1, n_oversamples: int = 10,
                    n_iter="auto", power_iteration_normalizer: str = "auto",
                    omega: np.ndarray | torch.Tensor | None = None, random_state=None,

@@ -8,7 +8,7 @@ bad = 0
 for i in range(N):
     m = int(rs0.choice([3, 9, 17, 64, 257, 1000, 4099, 20000, 70000, 300001, 524288])); n = int(rs0.choice([2, 3, 5, 24, 96, 130, 300, 700]))
     if m > 100000 and n > 300: n = 300
-    k = int(rs0.randint(1, min(m, n, 60) + 1)); kind = ["gauss", "lowrank", "deficient", "offset", "graded", "offsetlow", "const"][i % 7]
+    k = int(rs0.randint(1, min(m, n, 60) + 1)); kind = ["gauss", "lowrank", "deficient", "offset", "graded", "offsetlow", "const", "huge", "tiny", "sparse", "dup"][i % 11]
     typ = "standard" if i % 3 else "randomized"
     rs = np.random.RandomState(5000 + i)
     if kind == "gauss": X = rs.standard_normal((m, n))
@@ -20,6 +20,11 @@ for i in range(N):
     elif kind == "offsetlow":
         r = max(1, min(m, n) // 4); X = 250.0 + 10 * rs.standard_normal((m, 1)) + rs.standard_normal((m, r)) @ (rs.standard_normal((r, n)) * (0.7 ** np.arange(r))[:, None])
     elif kind == "const": X = np.full((m, n), 3.5) + (1e-3 * rs.standard_normal((m, n)) if i % 2 else 0)
+    elif kind == "huge": X = 1e22 * rs.standard_normal((m, min(n, 4))) @ rs.standard_normal((min(n, 4), n))
+    elif kind == "tiny": X = 1e-24 * rs.standard_normal((m, min(n, 4))) @ rs.standard_normal((min(n, 4), n))
+    elif kind == "sparse": X = rs.standard_normal((m, n)) * (rs.rand(m, n) < 0.05)
+    elif kind == "dup":
+        X = rs.standard_normal((m, n)); X[:, n // 2:] = X[:, : n - n // 2]
     else: X = rs.standard_normal((m, n)) * (0.7 ** np.arange(n))
     X = X.astype(np.float32)
     try:
@@ -27,7 +32,7 @@ for i in range(N):
     except Exception as e:
         print("EXC", i, m, n, k, kind, typ, repr(e)[:200]); bad += 1; continue
     X64 = X.astype(np.float64); sref = np.linalg.svd(X64, compute_uv=False); kk = min(k, m, n)
-    exact = typ == "standard" or kind in ("lowrank", "deficient", "offsetlow", "const")
+    exact = typ == "standard" or kind in ("lowrank", "deficient", "offsetlow", "const", "huge", "tiny")
     ds = np.abs(s - sref[:kk]).max() / sref[0]
     err = np.linalg.norm(X64 - (U.astype(np.float64) * s) @ V.astype(np.float64)); opt = np.sqrt((sref[kk:] ** 2).sum())
     live = s > 1e-4 * s[0]; Ul = U[:, live].astype(np.float64)

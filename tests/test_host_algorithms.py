@@ -208,3 +208,17 @@ def test_uncentred_data_with_delay_embedding(d):
     assert np.abs(r.s.numpy() / se - 1).max() < 2e-6
     assert col_cosines(r.Ut.numpy().T, Ue).min() > 1 - 1e-5
     assert col_cosines(r.Vh.numpy().T, Ve.T).min() > 1 - 1e-5
+
+
+@pytest.mark.parametrize("scale", [1e22, 1e-24])
+def test_extreme_magnitudes_are_rescaled(scale):
+    """|x| ~ 1e22 (squares overflow fp32) / 1e-24 (they underflow): scaled by a power of two for
+    the factorisation, like LAPACK's xLASCL; the caller's matrix comes back bit-identical."""
+    X = (orc.lowrank_matrix(700, 48, 20, 2).astype(np.float64) * scale).astype(np.float32)
+    sref = np.linalg.svd(X.astype(np.float64), compute_uv=False)[:6]
+    for fn, kw in ((dsvd.svd_snapshots, {}), (dsvd.svd_randomized, {"random_state": 0})):
+        Xt = _xt(X)
+        keep = Xt.clone()
+        r = fn(Xt, 6, kern=K, **kw)
+        assert "rescaled_by" in r.info and torch.equal(Xt, keep)
+        assert np.allclose(r.s.numpy(), sref, rtol=1e-5)

@@ -170,18 +170,20 @@ __device__ unsigned long long dmdx_stamp[8];
 // DMA = false: everything register-staged with scalar loads (any alignment).
 // ABL: timing-only ablations for diagnosis (results are wrong when ABL != 0):
 //   1 no global->LDS staging, 2 no barrier, 8 no chain fold (none of them changes an address).  Selected by DMDX_TN_ABLATE.
-// SK ("skinny rows"): 64 x 128 output tile, the four waves side by side (each 64 rows x 32
-//   columns = 2 x 1 MFMA blocks) -- for D with few rows (Z = X^T Y with l <= 64 columns of Y):
-//   half the MFMA work of a 128-row tile that would be half padding.
+// SK ("skinny rows", 0 / 2 / 3): a (32 SK) x 128 output tile, the four waves side by side (each
+//   32 SK rows x 32 columns = SK x 1 MFMA blocks) -- for D with few rows (Z = X^T Y with l <= 64
+//   or 64 < l <= 96 columns of Y): half / three quarters of the MFMA work of a 128-row tile that
+//   would be padding for the rest.
 // One work unit: the K-range of `split` of the TM x 128 output tile at (row0, col0) (D rows <-
 // columns of A, D cols <- columns of B), written as fp64 into the partial tile Pt.
 // lds: 2 stages of (TM + 128) x 32 floats.
-template <bool DMA, int ABL, bool SK>
+template <bool DMA, int ABL, int SK>
 __device__ __forceinline__ void tn_unit(const TnParams& p, const int split, const int row0, const int col0,
                                         double* Pt, float* lds) {
-  constexpr int TM = SK ? 64 : BT;   // tile rows    (columns of OpA)
-  constexpr int NI = SK ? 1 : 2;     // 32-column MFMA blocks per wave
-  constexpr int NPA = SK ? 2 : 4;    // 1 KiB pieces of the A panel per wave (or 16 B pieces per thread)
+  constexpr int TM = SK ? 32 * SK : BT;  // tile rows    (columns of OpA)
+  constexpr int MI = SK ? SK : 2;        // 32-row MFMA blocks per wave
+  constexpr int NI = SK ? 1 : 2;         // 32-column MFMA blocks per wave
+  constexpr int NPA = TM / 32;           // 1 KiB pieces of the A panel per wave (or 16 B pieces per thread)
   constexpr int OPA = TM * BK, OPB = BT * BK, STG = OPA + OPB;  // floats per stage
   // stage st: A panel at lds + st * STG, B panel at lds + st * STG + OPA
 
@@ -247,9 +249,9 @@ __device__ __forceinline__ void tn_unit(const TnParams& p, const int split, cons
 #pragma unroll
   for (int i = 0; i < NPA; ++i) aoffb[i] = 4u * aoff[i] + 3072u - 1024u * i;
 
-  f32x16 acc[2][NI];
+  f32x16 acc[MI][NI];
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
+  for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
@@ -264,9 +266,9 @@ __device__ __forceinline__ void tn_unit(const TnParams& p, const int split, cons
   // into an fp64 tile in HBM instead cost 4.6 % -- ~115 VALU/VMEM instructions per fold,
   // each of which waits for an MFMA slot while the SIMD's other wave streams MFMAs.)
   // At the end of the unit acc + acc2 is stored once, as fp64, into the unit's partial tile.
-  f32x16 acc2[2][NI];
+  f32x16 acc2[MI][NI];
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
+  for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
@@ -293,6 +295,7 @@ __device__ __forceinline__ void tn_unit(const TnParams& p, const int split, cons
       DMDX_COMMIT(0, NI - 1);                                                     \
       DMDX_COMMIT(1, NI - 1);                                                     \
     }                                                                             \
+    if constexpr (MI == 3) DMDX_COMMIT(MI - 1, 0);                                \
   } while (0)
 
   if (nchunks <= 0) {  // empty split: the partial tile must still be defined
@@ -332,6 +335,13 @@ __device__ __forceinline__ void tn_unit(const TnParams& p, const int split, cons
                "global_load_lds_dwordx4 %[a3], %[ap_] offset:3072"                                 \
                :: [la_] "s"(la), [ap_] "s"(ptr), [a0] "v"(o0), [a1] "v"(o1), [a2] "v"(o2), [a3] "v"(o3) \
                : "memory")
+#define DMDX_DMA_OP3(ptr, la, o0, o1, o2)                                                          \
+  asm volatile("s_mov_b32 m0, %[la_]\n\ts_nop 0\n\t"                                               \
+               "global_load_lds_dwordx4 %[a0], %[ap_]\n\t"                                         \
+               "global_load_lds_dwordx4 %[a1], %[ap_] offset:1024\n\t"                             \
+               "global_load_lds_dwordx4 %[a2], %[ap_] offset:2048"                                 \
+               :: [la_] "s"(la), [ap_] "s"(ptr), [a0] "v"(o0), [a1] "v"(o1), [a2] "v"(o2)           \
+               : "memory")
 #define DMDX_DMA_OP2(ptr, la, o0, o1)                                                              \
   asm volatile("s_mov_b32 m0, %[la_]\n\ts_nop 0\n\t"                                               \
                "global_load_lds_dwordx4 %[a0], %[ap_]\n\t"                                         \
@@ -341,6 +351,7 @@ __device__ __forceinline__ void tn_unit(const TnParams& p, const int split, cons
 #define DMDX_DMA_A(ap, la)                                                                         \
   do {                                                                                             \
     if constexpr (NPA == 4) DMDX_DMA_OP4(ap, la, aoffb[0], aoffb[1], aoffb[NPA - 2], aoffb[NPA - 1]); \
+    else if constexpr (NPA == 3) DMDX_DMA_OP3(ap, la, aoffb[0], aoffb[1], aoffb[NPA - 1]);         \
     else DMDX_DMA_OP2(ap, la, aoffb[0], aoffb[1]);                                                 \
   } while (0)
 #define DMDX_DMA_B(bp, lb) DMDX_DMA_OP4(bp, lb, boffb[0], boffb[1], boffb[2], boffb[3])
@@ -368,7 +379,7 @@ __device__ __forceinline__ void tn_unit(const TnParams& p, const int split, cons
   // ---- MFMA operand fragments, two register sets: the set for k-step t+1 is read from
   // LDS while the 16 MFMAs of k-step t run.  Lane (r = lane&31, h = lane>>5) reads, for
   // k-step t, the 16-byte k-chunk (2t + h) of its column, stored at slot (2t+h) ^ swz.
-  f32x4 fa0[2], fb0[NI], fa1[2], fb1[NI];
+  f32x4 fa0[MI], fb0[NI], fa1[MI], fb1[NI];
   int foff[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) foff[t] = l31 * BK + 4 * ((2 * t + lh) ^ swz(l31));
@@ -379,6 +390,7 @@ __device__ __forceinline__ void tn_unit(const TnParams& p, const int split, cons
     const float* bs_ = lds + (st) * STG + OPA + frag_b + foff[t];                    \
     FA[0] = *reinterpret_cast<const f32x4*>(as_);                                    \
     FA[1] = *reinterpret_cast<const f32x4*>(as_ + 32 * BK);                          \
+    if constexpr (MI == 3) FA[MI - 1] = *reinterpret_cast<const f32x4*>(as_ + 64 * BK); \
     FB[0] = *reinterpret_cast<const f32x4*>(bs_);                                    \
     if constexpr (NI == 2) FB[NI - 1] = *reinterpret_cast<const f32x4*>(bs_ + 32 * BK); \
   } while (0)
@@ -400,18 +412,18 @@ __device__ __forceinline__ void tn_unit(const TnParams& p, const int split, cons
 
 #define DMDX_MFMA4(FA, FB, j)                                                                   \
   do {                                                                                          \
-    _Pragma("unroll") for (int mi_ = 0; mi_ < 2; ++mi_)                                         \
+    _Pragma("unroll") for (int mi_ = 0; mi_ < MI; ++mi_)                                        \
         _Pragma("unroll") for (int ni_ = 0; ni_ < NI; ++ni_) acc[mi_][ni_] =                    \
             __builtin_amdgcn_mfma_f32_32x32x2f32(FA[mi_][j], FB[ni_][j], acc[mi_][ni_], 0, 0, 0); \
   } while (0)
-  // k-step: [2 + NI ds_read of the next fragments] 8 * NI MFMA
+  // k-step: [MI + NI ds_read of the next fragments] 4 * MI * NI MFMA
 #define DMDX_KSTEP(FA, FB, i)                                      \
   do {                                                             \
     DMDX_MFMA4(FA, FB, 0);                                         \
     DMDX_MFMA4(FA, FB, 1);                                         \
     DMDX_MFMA4(FA, FB, 2);                                         \
     DMDX_MFMA4(FA, FB, 3);                                         \
-    __builtin_amdgcn_sched_group_barrier(0x008, 8 * NI, 0);        \
+    __builtin_amdgcn_sched_group_barrier(0x008, 4 * MI * NI, 0);   \
   } while (0)
 
 #ifdef DMDX_STAMPS
@@ -426,13 +438,13 @@ __device__ __forceinline__ void tn_unit(const TnParams& p, const int split, cons
     const int phase = c & (FOLD / 4 - 1), fq = (c / (FOLD / 4)) & 3;
     DMDX_STAMP(st1);
     DMDX_READ_FRAGS(fa1, fb1, cur, 1);
-    __builtin_amdgcn_sched_group_barrier(0x100, 2 + NI, 0);   // ds_reads of the next fragments
+    __builtin_amdgcn_sched_group_barrier(0x100, MI + NI, 0);   // ds_reads of the next fragments
     DMDX_KSTEP(fa0, fb0, 0);
     DMDX_READ_FRAGS(fa0, fb0, cur, 2);
-    __builtin_amdgcn_sched_group_barrier(0x100, 2 + NI, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, MI + NI, 0);
     DMDX_KSTEP(fa1, fb1, 1);
     DMDX_READ_FRAGS(fa1, fb1, cur, 3);
-    __builtin_amdgcn_sched_group_barrier(0x100, 2 + NI, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, MI + NI, 0);
     DMDX_KSTEP(fa0, fb0, 2);
     DMDX_STAMP(st2);
 
@@ -443,12 +455,15 @@ __device__ __forceinline__ void tn_unit(const TnParams& p, const int split, cons
     cur ^= 1;
     DMDX_STAMP(st3);
     if (has_next) DMDX_READ_FRAGS(fa0, fb0, cur, 0);
-    __builtin_amdgcn_sched_group_barrier(0x100, 2 + NI, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, MI + NI, 0);
     DMDX_KSTEP(fa1, fb1, 3);
     if (!(ABL & 8) && phase == FOLD / 4 - 1) {
       switch (fq) {
         case 0: DMDX_FOLD(0, 0); break;
-        case 1: if constexpr (NI == 2) { DMDX_FOLD(0, NI - 1); } break;
+        case 1:
+          if constexpr (NI == 2) { DMDX_FOLD(0, NI - 1); }
+          else if constexpr (MI == 3) { DMDX_FOLD(MI - 1, 0); }
+          break;
         case 2: DMDX_FOLD(1, 0); break;
         default: if constexpr (NI == 2) { DMDX_FOLD(1, NI - 1); } break;
       }
@@ -478,6 +493,7 @@ __device__ __forceinline__ void tn_unit(const TnParams& p, const int split, cons
 #undef DMDX_DMA_B
 #undef DMDX_DMA_OP4
 #undef DMDX_DMA_OP2
+#undef DMDX_DMA_OP3
 #undef DMDX_FOLD
 #undef DMDX_COMMIT_ALL
 #undef DMDX_COMMIT
@@ -492,23 +508,24 @@ __device__ __forceinline__ int xcd_unit(int b, int total) {
   return ((g << 9) + 512 <= total) ? (g << 9) + (b & 7) * 64 + ((b & 511) >> 3) : b;
 }
 
-template <bool DMA, int ABL = 0, bool SK = false>
+template <bool DMA, int ABL = 0, int SK = 0>
 __global__ __launch_bounds__(NTH, 2) void gemm_tn_partial_kernel(TnParams p) {
-  __shared__ __attribute__((aligned(16))) float lds[2 * ((SK ? 64 : BT) + BT) * BK];
+  constexpr int TM = SK ? 32 * SK : BT;
+  __shared__ __attribute__((aligned(16))) float lds[2 * (TM + BT) * BK];
   const int pos = xcd_unit(blockIdx.x, gridDim.x);
   const int split = pos / p.ntiles;
   const int tile = pos - split * p.ntiles;
   int ta, tb;
   decode_tile(p, tile, ta, tb);
-  double* Pt = p.P + ((size_t)split * p.ntiles + tile) * ((SK ? 64 : BT) * BT);
-  tn_unit<DMA, ABL, SK>(p, split, ta * (SK ? 64 : BT), tb * BT, Pt, lds);
+  double* Pt = p.P + ((size_t)split * p.ntiles + tile) * (TM * BT);
+  tn_unit<DMA, ABL, SK>(p, split, ta * TM, tb * BT, Pt, lds);
 }
 
 // D (+)= sum_j A_j^T B_j over a batch of row blocks (TnBatch); p carries what the blocks share
 // (shape of D, tiles, P).  SYRK: A_j == B_j, triangle tiles.
-template <bool DMA, bool SK = false>
+template <bool DMA, int SK = 0>
 __global__ __launch_bounds__(NTH, 2) void syrk_batch_kernel(TnParams p, TnBatch bt) {
-  constexpr int TM = SK ? 64 : BT;
+  constexpr int TM = SK ? 32 * SK : BT;
   __shared__ __attribute__((aligned(16))) float lds[2 * (TM + BT) * BK];
   const int b = blockIdx.x;
   int j = 0;
@@ -539,7 +556,7 @@ __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(
     const double* P, int nsplit, int ntiles, int ntr, int ntc, int syrk, int nrow, int ncol,
     double* D64, int64_t ld64, float* D32, int64_t ld32, int accumulate, int tm) {
   __shared__ double tr[32][33];
-  // one workgroup per (tile, 32x32 sub-block); a tile is tm (64 or 128) rows x 128 columns
+  // one workgroup per (tile, 32x32 sub-block); a tile is tm (64, 96 or 128) rows x 128 columns
   const int nsb = (tm / 32) * 4;
   const int tile = blockIdx.x / nsb;
   const int sb = blockIdx.x - tile * nsb;
@@ -602,7 +619,7 @@ __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(
 }
 
 struct Plan {
-  int tm;  // tile rows: 128, or 64 when that halves the row padding of a non-SYRK product
+  int tm;  // tile rows: 128, or 96 / 64 when that cuts the row padding of a non-SYRK product
   int ntr, ntc, ntiles, nsplit, chunks_total, chunks_per_split;
   size_t ws_bytes;
 };
@@ -610,7 +627,14 @@ struct Plan {
 // share: number of equally sized row blocks that share the launch (batched SYRK)
 Plan make_plan(int64_t K, int64_t nrow, int64_t ncol, int syrk, int share = 1) {
   Plan pl;
-  pl.tm = (!syrk && ((nrow - 1) % BT) < 64) ? 64 : BT;
+  pl.tm = BT;
+  if (!syrk) {  // fewest padded rows; ties go to the taller tile (fewer re-reads of the B panels)
+    int64_t best = (nrow + BT - 1) / BT * BT;
+    for (int tm : {96, 64}) {
+      const int64_t padded = (nrow + tm - 1) / tm * tm;
+      if (padded < best) { best = padded; pl.tm = tm; }
+    }
+  }
   pl.ntr = (int)((nrow + pl.tm - 1) / pl.tm);
   pl.ntc = (int)((ncol + BT - 1) / BT);
   pl.ntiles = syrk ? pl.ntr * (pl.ntr + 1) / 2 : pl.ntr * pl.ntc;
@@ -679,11 +703,15 @@ int run_tn(const float* A, int64_t lda, const float* B, int64_t ldb, int64_t K, 
   else if (aligned && abl == 11)
     hipLaunchKernelGGL((gemm_tn_partial_kernel<true, 11>), grid, dim3(NTH), 0, stream, p);
   else if (aligned && pl.tm == 64)  // LDS-DMA staging needs 16-byte aligned column starts
-    hipLaunchKernelGGL((gemm_tn_partial_kernel<true, 0, true>), grid, dim3(NTH), 0, stream, p);
+    hipLaunchKernelGGL((gemm_tn_partial_kernel<true, 0, 2>), grid, dim3(NTH), 0, stream, p);
+  else if (aligned && pl.tm == 96)
+    hipLaunchKernelGGL((gemm_tn_partial_kernel<true, 0, 3>), grid, dim3(NTH), 0, stream, p);
   else if (aligned)
     hipLaunchKernelGGL(gemm_tn_partial_kernel<true>, grid, dim3(NTH), 0, stream, p);
   else if (pl.tm == 64)
-    hipLaunchKernelGGL((gemm_tn_partial_kernel<false, 0, true>), grid, dim3(NTH), 0, stream, p);
+    hipLaunchKernelGGL((gemm_tn_partial_kernel<false, 0, 2>), grid, dim3(NTH), 0, stream, p);
+  else if (pl.tm == 96)
+    hipLaunchKernelGGL((gemm_tn_partial_kernel<false, 0, 3>), grid, dim3(NTH), 0, stream, p);
   else
     hipLaunchKernelGGL(gemm_tn_partial_kernel<false>, grid, dim3(NTH), 0, stream, p);
   DMDX_LAUNCH_CHECK();
@@ -753,11 +781,14 @@ int run_batch(const float* const* A, const int64_t* lda, const float* const* B, 
     p.P = reinterpret_cast<double*>(ws);
     const dim3 grid((unsigned)units);
     if (pl.tm == 64) {
-      if (aligned) hipLaunchKernelGGL((syrk_batch_kernel<true, true>), grid, dim3(NTH), 0, stream, p, bt);
-      else hipLaunchKernelGGL((syrk_batch_kernel<false, true>), grid, dim3(NTH), 0, stream, p, bt);
+      if (aligned) hipLaunchKernelGGL((syrk_batch_kernel<true, 2>), grid, dim3(NTH), 0, stream, p, bt);
+      else hipLaunchKernelGGL((syrk_batch_kernel<false, 2>), grid, dim3(NTH), 0, stream, p, bt);
+    } else if (pl.tm == 96) {
+      if (aligned) hipLaunchKernelGGL((syrk_batch_kernel<true, 3>), grid, dim3(NTH), 0, stream, p, bt);
+      else hipLaunchKernelGGL((syrk_batch_kernel<false, 3>), grid, dim3(NTH), 0, stream, p, bt);
     } else {
-      if (aligned) hipLaunchKernelGGL((syrk_batch_kernel<true, false>), grid, dim3(NTH), 0, stream, p, bt);
-      else hipLaunchKernelGGL((syrk_batch_kernel<false, false>), grid, dim3(NTH), 0, stream, p, bt);
+      if (aligned) hipLaunchKernelGGL((syrk_batch_kernel<true, 0>), grid, dim3(NTH), 0, stream, p, bt);
+      else hipLaunchKernelGGL((syrk_batch_kernel<false, 0>), grid, dim3(NTH), 0, stream, p, bt);
     }
     DMDX_LAUNCH_CHECK();
     hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3(pl.ntiles * (pl.tm / 32) * 4), dim3(256), 0, stream, p.P, slabs,

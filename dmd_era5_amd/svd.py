@@ -252,6 +252,12 @@ def top_eigh(G: torch.Tensor, l: int, method: str = "auto", tol: float = 1e-9,
 BLOCK_ROWS = 131072
 
 
+def _pitched(kern, Wt: torch.Tensor) -> torch.Tensor:
+    """The small operand of K2, re-pitched ONCE for all row blocks (HipKernels.pitch)."""
+    fn = getattr(kern, "pitch", None)
+    return fn(Wt) if fn is not None else Wt
+
+
 def split_rows(m: int, block_rows: int | None = None) -> list[tuple[int, int]]:
     """[(start, stop)] of nearly equal row blocks, each a multiple of 4 rows when m is."""
     block_rows = block_rows or BLOCK_ROWS
@@ -486,7 +492,8 @@ def svd_snapshots(Xt, n_components: int, delay: int = 1, oversample: int | None 
             # fixes them up to the rounding of those products (~1e-7 s_1 / s_j relative); the
             # Rayleigh-Ritz below then runs on the un-normalised E V.
             Eb = [embed_view(B, delay) for B in blocks]
-            Yb = [kern.skinny(E, V.T.contiguous().to(torch.float32)) for E in Eb]
+            Vt32 = _pitched(kern, V.T.contiguous().to(torch.float32))
+            Yb = [kern.skinny(E, Vt32) for E in Eb]
             if mus is not None:   # E = A + mu~ 1^T on the centred blocks: Y += mu~ (1^T V)
                 ones_v = V.sum(dim=0).to(torch.float32)
                 for Y, mu in zip(Yb, mus):
@@ -519,7 +526,7 @@ def svd_snapshots(Xt, n_components: int, delay: int = 1, oversample: int | None 
         s0 = torch.where(good, s0, torch.zeros_like(s0))
         t2 = _sync_time(dev) if timings else 0.0
 
-        Wt = (V * inv_s0).T.contiguous().to(torch.float32)           # (l, nd)
+        Wt = _pitched(kern, (V * inv_s0).T.contiguous().to(torch.float32))  # (l, nd)
         Up = [kern.skinny(embed_view(B, delay), Wt) for B in blocks]  # (l, d*mb): U' = X V S^-1
         if mus is not None:   # + mu~ (1^T V) S^-1: the part of E the centred blocks no longer hold
             cvec = (V.sum(dim=0) * inv_s0).to(torch.float32)
@@ -541,7 +548,7 @@ def svd_snapshots(Xt, n_components: int, delay: int = 1, oversample: int | None 
             ok = s > s0[0] * 1e-7 if (mus is None and not polish) else s > s[0] * 1e-7
             inv_s = torch.where(ok, 1.0 / torch.where(ok, s, torch.ones_like(s)), torch.zeros_like(s))
             Rm = (s0[:, None] * Z) * inv_s[None, :]                   # (l, k): U = U' R
-            Rt = Rm.T.contiguous().to(torch.float32)
+            Rt = _pitched(kern, Rm.T.contiguous().to(torch.float32))
             Ub = [kern.skinny(U, Rt) for U in Up]                     # (k, d*mb)
             Vh = (V @ Z).T.contiguous()
         else:
@@ -600,7 +607,7 @@ def _cholqr(Yb, comm: Comm, kern, passes: int = 1):
                 raise np.linalg.LinAlgError("CholeskyQR: the Gram matrix of the range-finder block is not finite")
             todo += 1
         Rinv = torch.linalg.solve_triangular(L.T, eye, upper=True)  # R = L^T
-        Rt = comm.broadcast_(Rinv.T.contiguous().to(torch.float32))
+        Rt = _pitched(kern, comm.broadcast_(Rinv.T.contiguous().to(torch.float32)))
         Yb = [kern.skinny(Y, Rt) for Y in Yb]
     return Yb
 
@@ -665,7 +672,8 @@ def svd_randomized(Xt, n_components: int, delay: int = 1, n_oversamples: int = 1
     t0 = _sync_time(dev) if timings else 0.0
 
     for _ in range(n_it):
-        Yb = [kern.skinny(E, Qt) for E in Eb]    # Y = X Q            (extmath.py:350)
+        Qp = _pitched(kern, Qt)
+        Yb = [kern.skinny(E, Qp) for E in Eb]    # Y = X Q            (extmath.py:350)
         if normalise:
             Yb = _cholqr(Yb, comm, kern)
         Zt = _gemm_tn_blocks(Eb, Yb, kern, comm)  # Z = X^T Y, (l, nd) (extmath.py:351)
@@ -674,13 +682,14 @@ def svd_randomized(Xt, n_components: int, delay: int = 1, n_oversamples: int = 1
         else:
             Qt = Zt.to(torch.float32)
         comm.broadcast_(Qt)
-    Yb = [kern.skinny(E, Qt) for E in Eb]        # extmath.py:355
+    Qp = _pitched(kern, Qt)
+    Yb = [kern.skinny(E, Qp) for E in Eb]        # extmath.py:355
     Qmb = _cholqr(Yb, comm, kern, passes=2)      # orthonormal basis of range(Y)
     Bm = _gemm_tn_blocks(Eb, Qmb, kern, comm)    # (l, nd) = Q^T X    (extmath.py:577)
     Uhat, s, Vh = torch.linalg.svd(Bm, full_matrices=False)
     Uhat, s, Vh = Uhat.contiguous(), s.contiguous(), Vh.contiguous()
     comm.broadcast_(Uhat, s, Vh)
-    Uk = Uhat[:, :k].T.contiguous().to(torch.float32)
+    Uk = _pitched(kern, Uhat[:, :k].T.contiguous().to(torch.float32))
     Ub = [kern.skinny(Q, Uk) for Q in Qmb]       # U = Q Uhat
     s = s[:k]
     Vh = Vh[:k].contiguous()

@@ -6,7 +6,7 @@ usage: summarize_profiles.py <raw dir> <out dir> <tag>
 """
 import csv, glob, json, os, shutil, sys
 
-GRAM = "syrk_batch_kernel<true, false>"             # the cfg2 Gram launch (all 8 row blocks, LDS-DMA)
+GRAM = "syrk_batch_kernel<true, 0>"                 # the cfg2 Gram launch (all 8 row blocks, LDS-DMA)
 M_BLOCK, N = 1038240, 8760                    # rows of X covered by one launch
 
 

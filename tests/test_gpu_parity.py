@@ -86,7 +86,8 @@ def test_syrk_large_properties(K):
 
 # ---------------------------------------------------------------- K3 GEMM_TN
 @pytest.mark.parametrize("K_,na,nb", [(64, 3, 2), (1000, 130, 60), (4097, 300, 70), (50000, 192, 220),
-                                       (3001, 257, 33), (20000, 140, 150), (777, 64, 64), (5000, 1000, 129)])
+                                       (3001, 257, 33), (20000, 140, 150), (777, 64, 64), (5000, 1000, 129),
+                                       (200000, 300, 90), (99999, 128, 96), (65536, 3653, 70)])   # 96-row tiles
 def test_gemm_tn(K, K_, na, nb):
     rs = np.random.RandomState(K_ + na + nb)
     A = _rand(rs, K_, na)
@@ -102,7 +103,7 @@ def test_gemm_tn(K, K_, na, nb):
 @pytest.mark.parametrize(
     "m,n,l",
     [(4, 2, 1), (512, 32, 32), (1000, 33, 50), (1003, 64, 64), (4096, 192, 60),
-     (5000, 191, 100), (3000, 100, 128), (2048, 77, 200), (130, 500, 7)],
+     (5000, 191, 100), (3000, 100, 128), (2048, 77, 200), (130, 500, 7), (8192, 3653, 70)],
 )
 def test_skinny(K, m, n, l):
     rs = np.random.RandomState(m + 13 * n + 7 * l)
@@ -394,10 +395,11 @@ def test_syrk_blocks_equals_sum_of_block_grams(K, sizes, n):
     assert np.all(np.abs(seq.cpu().numpy() - G) <= 4e-6 * absref + 1e-30)
 
 
-@pytest.mark.parametrize("sizes,na,nb", [([5000, 3000, 4097], 60, 260), ([700] * 19, 70, 200), ([30001, 29999], 130, 129)])
+@pytest.mark.parametrize("sizes,na,nb", [([5000, 3000, 4097], 60, 260), ([700] * 19, 70, 200), ([30001, 29999], 130, 129),
+                                         ([40000] * 5 + [39996], 200, 80), ([8191, 4093], 129, 65)])
 def test_gemm_tn_blocks_equals_sum_of_block_products(K, sizes, na, nb):
     """dmdx_gemm_tn_blocks_f32 against the fp64 product of the stacked rows: ragged block sizes,
-    > 16 blocks, 64-row and 128-row tiles, accumulation into an existing C."""
+    > 16 blocks, 64-, 96- and 128-row tiles, accumulation into an existing C."""
     rs = np.random.RandomState(sum(sizes) + na + nb)
     As = [_rand(rs, m, na) for m in sizes]
     Bs = [_rand(rs, m, nb) for m in sizes]

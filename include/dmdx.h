@@ -91,9 +91,13 @@ int dmdx_gemm_tn_blocks_f32(const float* const* A, const int64_t* lda, const flo
                             void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- K2: tall-skinny Y = X W -----------------------------------------------
- * X: m x n (ldx, rows > ldx allowed), W: n x l (ldw), Y: m x l (ldy), l <= 256.
+ * X: m x n (ldx, rows > ldx allowed), W: n x l (ldw), Y: m x l (ldy); l is processed in column
+ * groups of 128 (X is re-read once per group).
  * U = X (V_r S^-1) of the method of snapshots and `A @ Q` of the range finder
- * (extmath.py:349,355).  */
+ * (extmath.py:349,355).  Fast path (16-byte loads of X, W and stores of Y): m, ldx, ldw, ldy
+ * multiples of 4 and X, W, Y 16-byte aligned; anything else takes the scalar-load path (same
+ * results, about half the rate).  When n % 4 != 0 give the small W a padded ldw rather than a
+ * tight one -- the Python host does (HipKernels.pitch). */
 int dmdx_gemm_nn_skinny_f32(const float* X, int64_t m, int64_t n, int64_t ldx,
                             const float* W, int64_t ldw, int64_t l,
                             float* Y, int64_t ldy, void* stream);

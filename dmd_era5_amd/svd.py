@@ -227,6 +227,14 @@ def top_eigh(G: torch.Tensor, l: int, method: str = "auto", tol: float = 1e-9,
             Y = Y - P @ (P.T @ Y)
         return _orth(Y)
 
+    # A sweep costs about as much as 1/45 of the full solver at n = 8760, b = 62 and relatively more
+    # for smaller n / wider blocks (measured: 18 / 9 / 5.5 ms per sweep against 816 / 142 / 50 ms of
+    # syevd at n = 8760 / 4000 / 2000): when the residual history forecasts more sweeps than twice
+    # that break-even (flat spectra -- pure noise has no gap for a Krylov method to use), stop
+    # early and solve the whole matrix.  The rule is a function of the residuals only, so every
+    # rank and every run takes the same branch.
+    break_even = min(float(max_outer), max(6.0, n / 200.0 * 62.0 / b))
+    prev = res
     for it in range(max_outer):
         Y1 = orth_against(G @ Q, Q)
         P = torch.cat([Q, Y1], dim=1)
@@ -235,6 +243,14 @@ def top_eigh(G: torch.Tensor, l: int, method: str = "auto", tol: float = 1e-9,
         th, Q, res = ritz(S, G @ S, b)
         if res <= tol:
             return done(th, Q, res, "krylov", it + 1)
+        if it >= 2:
+            rate = res / prev if prev > 0 else 1.0
+            need = math.inf if not (0.0 < rate < 1.0) else math.log(tol / res) / math.log(rate)
+            if it + 1 + need > 2.0 * break_even:
+                if info is not None:
+                    info["eig_krylov_forecast_sweeps"] = float(min(need, 1e9))
+                break
+        prev = res
     if info is not None:
         info["eig_krylov_failed_residual"] = res
     return top_eigh(G, l, method="full", info=info, kern=kern)

@@ -61,6 +61,19 @@ def test_top_eigh_power_fast_path_on_lowrank_plus_noise():
     assert (V_p * V_f).sum(dim=0).abs().min() > 1 - 1e-8
 
 
+def test_top_eigh_flat_spectrum_goes_to_the_full_solver_early():
+    """Pure noise has no spectral gap: the residual history forecasts far more Krylov sweeps than
+    the full solver costs, so the sweeps stop after a few and the answer comes from eigh."""
+    rs = np.random.RandomState(2)
+    A = rs.standard_normal((6000, 1800))
+    G = torch.from_numpy(A.T @ A)
+    info = {}
+    lam_a, V_a = dsvd.top_eigh(G, 20, method="krylov", info=info, kern=K)
+    lam_f, V_f = dsvd.top_eigh(G, 20, method="full")
+    assert info["eig_method"] == "full" and info["eig_krylov_forecast_sweeps"] > 18
+    assert torch.equal(lam_a, lam_f) and torch.equal(V_a, V_f)
+
+
 def test_randomized_same_omega_as_sklearn():
     g = np.load(os.path.join(GOLDEN, "lowrank_4096x192.npz"))
     X = orc.lowrank_matrix(4096, 192, 100, 0)

@@ -58,3 +58,22 @@ def add_download_attributes(ds: Dataset, parsed_config: dict) -> Dataset:
     ds.attrs["levels"] = parsed_config["levels"]
     ds.attrs["date_downloaded"] = datetime.now().isoformat()
     return ds
+
+
+def create_mock_era5_svd(start_datetime="2020-01-01", end_datetime="2020-01-02", variables=None, levels=None,
+                         mean_center: bool = True, scale: bool = False, delay_embedding: int = 2,
+                         n_components: int = 6, seed=None):
+    """Mock SVD results for tests of the result schema (mirror of the reference's helper,
+    create_mock_data.py:158-221): mock slice -> standardize -> flatten -> delay embedding ->
+    rank-``n_components`` SVD.  Returns ``(U, s, V, coords, X)`` with ``X`` the embedded
+    (space, time) array.  The reference calls ``np.linalg.svd`` here; this one goes through
+    ``svd_on_era5`` like everything else, i.e. it needs the GPU."""
+    from .era5_svd import svd_on_era5
+    from .slice_tools import apply_delay_embedding, flatten_era5_variables, standardize_data
+
+    ds = create_mock_era5(start_datetime, end_datetime, variables or ["temperature"], levels or [1000], seed=seed)
+    if mean_center:
+        ds, _, _ = standardize_data(ds, scale=scale)
+    da = apply_delay_embedding(flatten_era5_variables(ds), delay_embedding)
+    U, s, V = svd_on_era5(da, {"svd_type": "standard", "n_components": n_components})
+    return U, s, V, da.coords, da

@@ -189,3 +189,32 @@ def test_main_uncentred_temperature_matches_oracle(svd_base_config, project_root
     assert np.linalg.norm(X64 - rec) <= (1 + 1e-4) * np.sqrt((sall[5:] ** 2).sum())
     U = res["U"].values.astype(np.float64)
     assert np.abs(U.T @ U - np.eye(5)).max() < 1e-4
+
+
+def test_create_mock_era5_svd_and_combine_like_the_reference_tests():
+    """reference tests/test_01_create_mock_data.py:33-53 and tests/test_03_era5_svd.py:179-225:
+    the mock-SVD helper's return types / shapes / coordinate keys, and the Dataset that
+    combine_svd_results builds from it (with and without the data matrix) -- plus the values
+    against numpy on the same seeded slice, which the reference's tests do not pin."""
+    from dmd_era5_amd.create_mock_data import create_mock_era5_svd
+    from dmd_era5_amd.era5_svd import combine_svd_results
+    from dmd_era5_amd.labeled import DataArray, Dataset
+
+    U, s, V, coords, X = create_mock_era5_svd(n_components=4, seed=21)
+    assert all(isinstance(a, np.ndarray) for a in (U, s, V)) and isinstance(X, DataArray)
+    assert U.shape[1] == 4 and s.size == 4 and V.shape[0] == 4
+    assert sorted(coords.keys()) == sorted(["space", "time", "original_variable", "delay"])
+    assert X.shape == (2 * 36 * 72, 24) and U.shape[0] == X.shape[0] and V.shape[1] == X.shape[1]
+    sr = np.linalg.svd(X.values, compute_uv=False)[:4]
+    assert np.allclose(s, sr, rtol=2e-5)
+
+    ds = combine_svd_results(U, s, V, coords)
+    assert isinstance(ds, Dataset) and sorted(ds.data_vars.keys()) == ["U", "V", "s"]
+    assert sorted(ds["U"].dims) == ["components", "space"] and list(ds["s"].dims) == ["components"]
+    assert sorted(ds["V"].dims) == ["components", "time"]
+    assert sorted(ds["U"].coords.keys()) == sorted(["space", "components", "original_variable", "delay"])
+    assert sorted(ds["s"].coords.keys()) == ["components"]
+    assert sorted(ds["V"].coords.keys()) == ["components", "time"]
+    dx = combine_svd_results(U, s, V, coords, X=X)
+    assert sorted(dx.data_vars.keys()) == ["U", "V", "X", "s"]
+    assert dx["U"].shape[0] == dx["X"].shape[0] and dx["V"].shape[1] == dx["X"].shape[1]

@@ -220,11 +220,22 @@ def plan_selection(ds: Dataset, levels, delta_time):
     return level_idx, np.asarray(levels), take, labels
 
 
-def _upload_variable(da: DataArray, level_idx, take, device, kern, center, scale, stats):
+def lat_band(nlat: int, rank: int, world: int) -> tuple[int, int]:
+    """Latitude rows [i0, i1) of rank ``rank``: the space points are sharded over the GPUs by
+    latitude band (every level and variable of the band lives on the same rank), bands of
+    nearly equal height."""
+    if world > nlat:
+        raise ValueError(f"{world} ranks for {nlat} latitude rows: use at most one rank per latitude row")
+    return rank * nlat // world, (rank + 1) * nlat // world
+
+
+def _upload_variable(da: DataArray, level_idx, take, device, kern, center, scale, stats, band=None):
     """One variable (time, level, lat, lon) -> centred/scaled row blocks (time, rows) in HBM.
 
     Streams time slabs: file/host -> pinned staging -> device slab -> strided device copy
-    into each row block.  Row order inside the variable: level slowest, longitude fastest."""
+    into each row block.  Row order inside the variable: level slowest, longitude fastest.
+    ``band`` = (i0, i1): only these latitude rows (this rank's shard); file-backed variables
+    are then read as hyperslabs, so a rank touches only its own bytes of the file."""
     import torch
 
     from . import svd as dsvd
@@ -233,13 +244,16 @@ def _upload_variable(da: DataArray, level_idx, take, device, kern, center, scale
     if order != [0, 1, 2, 3]:
         raise ValueError(f"variable {da.name}: expected dims (time, level, latitude, longitude), got {da.dims}")
     n = len(take)
-    nlev_all, nlat, nlon = da.shape[1:]
+    nlev_all, nlat_all, nlon = da.shape[1:]
+    i0, i1 = band if band is not None else (0, nlat_all)
+    nlat = i1 - i0
+    whole = (i0, i1) == (0, nlat_all)
     m_v = len(level_idx) * nlat * nlon
     ranges = dsvd.split_rows(m_v)
     blocks = [torch.empty((n, b - a), dtype=torch.float32, device=device) for a, b in ranges]
     lazy = da.lazy
     host = None if lazy is not None else da.values
-    rows = max(1, SLAB_BYTES // max(1, nlev_all * nlat * nlon * 4))
+    rows = max(1, SLAB_BYTES // max(1, nlev_all * max(nlat, 1) * nlon * 4))
     contiguous = np.array_equal(take, np.arange(take[0], take[0] + n)) if n else True
     all_levels = len(level_idx) == nlev_all and np.array_equal(level_idx, np.arange(nlev_all))
     nbytes = 0
@@ -247,7 +261,12 @@ def _upload_variable(da: DataArray, level_idx, take, device, kern, center, scale
     # straight into one of two pinned staging buffers and copied to the device asynchronously,
     # so the next read overlaps the previous host->device copy
     direct = lazy is not None and contiguous and all_levels and lazy.dtype == np.float32
-    pinned = [torch.empty((rows, m_v), dtype=torch.float32).pin_memory() for _ in range(2)] if direct else None
+    on_gpu = device.type == "cuda"
+    pinned = None
+    if direct:
+        pinned = [torch.empty((rows, m_v), dtype=torch.float32) for _ in range(2)]
+        if on_gpu:
+            pinned = [b.pin_memory() for b in pinned]
     events = [None, None]
     for it, j0 in enumerate(range(0, n, rows)):
         j1 = min(n, j0 + rows)
@@ -255,21 +274,27 @@ def _upload_variable(da: DataArray, level_idx, take, device, kern, center, scale
             buf = pinned[it & 1]
             if events[it & 1] is not None:
                 events[it & 1].synchronize()        # the copy that last used this buffer is done
-            view = buf[: j1 - j0].numpy().reshape((j1 - j0,) + tuple(lazy.shape[1:]))
-            lazy.read_slab(int(take[j0]), int(take[j1 - 1]) + 1, view)
+            view = buf[: j1 - j0].numpy().reshape((j1 - j0, nlev_all, nlat, nlon))
+            if whole:
+                lazy.read_slab(int(take[j0]), int(take[j1 - 1]) + 1, view)
+            else:
+                lazy.read_box((int(take[j0]), 0, i0, 0), (j1 - j0, nlev_all, nlat, nlon), view)
             dev = buf[: j1 - j0].to(device, non_blocking=True)
             nbytes += (j1 - j0) * m_v * 4
         else:
+            def read(lo, hi):
+                if lazy is None:
+                    return host[lo:hi] if whole else host[lo:hi, :, i0:i1]
+                if whole:
+                    return lazy.read_slab(lo, hi)
+                return lazy.read_box((lo, 0, i0, 0), (hi - lo, nlev_all, nlat, nlon))
+
             if contiguous:
-                t0, t1 = int(take[j0]), int(take[j1 - 1]) + 1
-                slab = lazy.read_slab(t0, t1) if lazy is not None else host[t0:t1]
+                slab = read(int(take[j0]), int(take[j1 - 1]) + 1)
             else:  # resampled: gather the selected snapshots
                 idx = take[j0:j1]
-                if lazy is not None:
-                    lo, hi = int(idx.min()), int(idx.max()) + 1
-                    slab = lazy.read_slab(lo, hi)[idx - lo]
-                else:
-                    slab = host[idx]
+                lo = int(idx.min())
+                slab = read(lo, int(idx.max()) + 1)[idx - lo]
             if not all_levels:
                 slab = slab[:, level_idx]
             slab = np.ascontiguousarray(slab.reshape(j1 - j0, m_v), dtype=np.float32)
@@ -277,7 +302,7 @@ def _upload_variable(da: DataArray, level_idx, take, device, kern, center, scale
             dev = torch.from_numpy(slab).to(device, non_blocking=False)
         for (a, b), Xb in zip(ranges, blocks):
             Xb[j0:j1].copy_(dev[:, a:b])
-        if direct:
+        if direct and on_gpu:
             events[it & 1] = torch.cuda.Event()
             events[it & 1].record()
         del dev
@@ -290,11 +315,21 @@ def _upload_variable(da: DataArray, level_idx, take, device, kern, center, scale
     return blocks, m_v, nbytes
 
 
-def _device_pipeline(ds: Dataset, parsed_config: dict):
+def _device_pipeline(ds: Dataset, parsed_config: dict, comm=None, kern=None, device=None):
     """Slice -> (U, s, V, coords, X, X_mean, X_std) with X resident only in HBM.
 
     Row order = the reference's flatten order (variable-major, then level, latitude,
-    longitude; ref slice_tools.py:311-336); embedding order k*m + s (ref :207-211)."""
+    longitude; ref slice_tools.py:311-336); embedding order k*m + s (ref :207-211).
+
+    ``comm`` (svd.TorchDistComm, one process per GPU): the space points are sharded by latitude
+    band (``lat_band``); each rank reads, centres and decomposes only its rows, the exchanges
+    are the small all-reduces inside the SVD, and the row-sharded results (U, the row means,
+    X if asked for) are gathered to rank 0's HOST memory in the global row order for the
+    NetCDF write.  Ranks other than 0 return U = X = X_mean = X_std = None.
+
+    ``kern`` / ``device``: the kernel provider and where the row blocks live -- the HIP kernels
+    on the current GPU unless a test injects its CPU double (main() never does: without
+    libdmdx.so or a GPU ``default_kernels()`` raises)."""
     import time as _time
 
     import torch
@@ -302,33 +337,38 @@ def _device_pipeline(ds: Dataset, parsed_config: dict):
     from . import svd as dsvd
     from .kernels import default_kernels
 
-    kern = default_kernels()
-    device = torch.device("cuda", torch.cuda.current_device())
+    comm = comm or dsvd.Comm()
+    root = comm.rank == 0
+    if kern is None:
+        kern = default_kernels()
+        device = torch.device("cuda", torch.cuda.current_device())
+    sync = torch.cuda.synchronize if device.type == "cuda" else (lambda: None)
     d = parsed_config["delay_embedding"]
     center, scale = parsed_config["mean_center"], parsed_config["scale"]
     names = list(ds.data_vars)
     level_idx, levels, take, time = plan_selection(ds, parsed_config["levels"], parsed_config["delta_time"])
     log_and_print(logger, f"Dataset slicing completed successfully using levels {list(levels)}")
     log_and_print(logger, f"Resampled the dataset with time delta: {parsed_config['delta_time']}")
-    one = space_labels(levels, ds.coords["latitude"].values, ds.coords["longitude"].values)
-    m_v = one.shape[0]
+    lats, lons = ds.coords["latitude"].values, ds.coords["longitude"].values
+    nlev, nlat, nlon = len(levels), len(lats), len(lons)
+    band = lat_band(nlat, comm.rank, comm.world_size) if comm.world_size > 1 else None
 
     t0 = _time.perf_counter()
     blocks, stats, total = [], {"mean": [], "std": []}, 0
     for name in names:
-        vb, mv, nbytes = _upload_variable(ds[name], level_idx, take, device, kern, center, scale, stats)
-        assert mv == m_v
+        vb, _, nbytes = _upload_variable(ds[name], level_idx, take, device, kern, center, scale, stats, band)
         blocks.extend(vb)
         total += nbytes
-    torch.cuda.synchronize()
+    sync()
     dt = _time.perf_counter() - t0
+    shard = f" (rank {comm.rank} of {comm.world_size}: latitude rows {band[0]}:{band[1]})" if band else ""
     log_and_print(logger, f"Ingest: {total / 1e9:.3f} GB to HBM in {dt:.2f} s ({total / 1e9 / max(dt, 1e-9):.2f} GB/s, "
-                          f"{len(blocks)} row blocks, centre/scale on device)")
+                          f"{len(blocks)} row blocks, centre/scale on device){shard}")
     k = parsed_config["n_components"]
     t0 = _time.perf_counter()
     if parsed_config["svd_type"] == "standard":
         log_and_print(logger, "Performing standard SVD...")
-        res = dsvd.svd_snapshots(blocks, k, delay=d)
+        res = dsvd.svd_snapshots(blocks, k, delay=d, comm=comm, kern=kern)
         if res.info.get("mean_deflated"):
             log_and_print(logger, "Un-centred data: SVD of the centred matrix + rank-one update for the time mean.")
         if res.info.get("warning"):
@@ -336,36 +376,98 @@ def _device_pipeline(ds: Dataset, parsed_config: dict):
         log_and_print(logger, "Standard SVD complete.")
     else:
         log_and_print(logger, "Performing randomized SVD...")
-        res = dsvd.svd_randomized(blocks, k, delay=d, **_engine_opts(parsed_config))
+        res = dsvd.svd_randomized(blocks, k, delay=d, comm=comm, kern=kern, **_engine_opts(parsed_config))
         log_and_print(logger, "Randomized SVD complete.")
-    torch.cuda.synchronize()
+    sync()
     dt = _time.perf_counter() - t0
     log_and_print(logger, f"SVD stage: {dt:.3f} s ({total / 1e9 / max(dt, 1e-9):.1f} GB/s of X)")
     src_dtype = ds[names[0]].dtype
     out_dtype = src_dtype if src_dtype in (np.float32, np.float64) else np.float64
-    U = res.Ut.cpu().numpy().T.astype(out_dtype, copy=False)
+
+    def assemble(t: "torch.Tensor", lead: tuple) -> np.ndarray | None:
+        """Rank-local (*lead, rows of this rank in (variable, level, band, lon) order) pieces ->
+        the global (*lead, variable, level, latitude, longitude) host array on rank 0."""
+        parts = comm.gather_to_root(t)
+        if parts is None:
+            return None
+        if len(parts) == 1:
+            return parts[0].numpy().reshape(lead + (len(names), nlev, nlat, nlon))
+        out = np.empty(lead + (len(names), nlev, nlat, nlon), dtype=parts[0].numpy().dtype)
+        for r, part in enumerate(parts):
+            j0, j1 = lat_band(nlat, r, comm.world_size)
+            out[..., j0:j1, :] = part.numpy().reshape(lead + (len(names), nlev, j1 - j0, nlon))
+        return out
+
+    kk = res.Ut.shape[0]
+    Ug = assemble(res.Ut, (kk, d))                       # local row order k_delay*m_loc + s_loc
+    U = None if Ug is None else Ug.reshape(kk, -1).T.astype(out_dtype, copy=False)
     s = res.s.cpu().numpy().astype(out_dtype, copy=False)
     V = res.Vh.cpu().numpy().astype(out_dtype, copy=False)
 
-    coords = delay_coords(np.tile(one, (len(names), 1)), np.repeat(names, m_v), time, d)
-    X = X_mean = X_std = None
+    coords = X = X_mean = X_std = None
+    if root:
+        one = space_labels(levels, lats, lons)
+        coords = delay_coords(np.tile(one, (len(names), 1)), np.repeat(names, one.shape[0]), time, d)
     if center and d > 1:  # the reference keeps the mean / std only in this case (ref :400-414)
-        mu = torch.cat(stats["mean"]).cpu().numpy().astype(out_dtype)
-        X_mean = DataArray(np.tile(mu, d), ("space",), {k_: coords[k_] for k_ in ("space", "original_variable")})
+        mu = assemble(torch.cat(stats["mean"]), ())
+        if root:
+            X_mean = DataArray(np.tile(mu.reshape(-1).astype(out_dtype), d), ("space",),
+                               {k_: coords[k_] for k_ in ("space", "original_variable")})
         if scale:
-            sd = torch.cat(stats["std"]).cpu().numpy().astype(out_dtype)
-            X_std = DataArray(np.tile(sd, d), ("space",), {k_: coords[k_] for k_ in ("space", "original_variable")})
+            sd = assemble(torch.cat(stats["std"]), ())
+            if root:
+                X_std = DataArray(np.tile(sd.reshape(-1).astype(out_dtype), d), ("space",),
+                                  {k_: coords[k_] for k_ in ("space", "original_variable")})
     if parsed_config["save_data_matrix"]:
         from .slice_tools import _apply_delay_embedding_np
 
-        Xc = np.concatenate([b.cpu().numpy() for b in blocks], axis=1).T.astype(out_dtype, copy=False)
-        X = DataArray(_apply_delay_embedding_np(np.asfortranarray(Xc), d), ("space", "time"), coords)
+        n = blocks[0].shape[0]
+        # one rank: concatenate on the host (a device-side cat would hold X twice in HBM)
+        Xall = torch.cat(blocks, dim=1) if comm.world_size > 1 else torch.cat([b.cpu() for b in blocks], dim=1)
+        Xg = assemble(Xall, (n,))                        # (time, variable, level, lat, lon) on rank 0
+        del Xall
+        if root:
+            Xc = Xg.reshape(n, -1).T.astype(out_dtype, copy=False)
+            X = DataArray(_apply_delay_embedding_np(np.asfortranarray(Xc), d), ("space", "time"), coords)
     return U, s, V, coords, X, X_mean, X_std
+
+
+def _dist_comm():
+    """The communicator of this process: single-rank unless it runs under
+    ``python -m torch.distributed.run --nproc-per-node N -m dmd_era5_amd.era5_svd`` (one process
+    per GPU, RCCL) or inside an already initialised ``torch.distributed`` job.  Returns
+    (comm, created) -- ``created``: the process group was made here and is torn down by main.
+    DMDX_DIST_BACKEND=gloo / DMDX_DEVICE=i: rehearsal knobs (several ranks on one GPU)."""
+    import os
+
+    import torch
+    import torch.distributed as dist
+
+    from . import svd as dsvd
+
+    if dist.is_available() and dist.is_initialized():
+        return (dsvd.TorchDistComm() if dist.get_world_size() > 1 else dsvd.Comm()), False
+    if int(os.environ.get("WORLD_SIZE", "1")) <= 1:
+        return dsvd.Comm(), False
+    dev = int(os.environ.get("DMDX_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    torch.cuda.set_device(dev)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    backend = os.environ.get("DMDX_DIST_BACKEND", "nccl")
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+    else:
+        dist.init_process_group(backend)
+    return dsvd.TorchDistComm(), True
 
 
 def main(config: dict | None = None, write_to_netcdf: bool = False, use_dvc: bool = False):
     """SVD of an ERA5 slice (ref :336-453).  Returns (results Dataset, added_to_dvc,
-    retrieved_from_dvc) -- the two flags are always False here (no DVC)."""
+    retrieved_from_dvc) -- the two flags are always False here (no DVC).
+
+    Under torch.distributed (one process per GPU) the space points are sharded over the ranks
+    (``_device_pipeline``); rank 0 assembles, returns and writes the results, the other ranks
+    return ``(None, False, False)`` -- unless the results were already on disk, which every
+    rank finds for itself."""
     _no_dvc(use_dvc)
     if config is None:
         config = config_reader("era5-svd")
@@ -396,20 +498,28 @@ def main(config: dict | None = None, write_to_netcdf: bool = False, use_dvc: boo
         log_and_print(logger, msg, "error")
         raise Exception(msg) from e
 
+    comm, created = _dist_comm()
     try:
         ds = ds[parsed_config["variables"]]
         # slice_era5_dataset(levels=...) and resample_era5_dataset(...) happen inside, as index
         # selections applied while the slice is streamed to the device
-        U, s, V, coords, X, X_mean, X_std = _device_pipeline(ds, parsed_config)
-        svd_results = combine_svd_results(U, s, V, coords, X=X, X_mean=X_mean, X_std=X_std)
-        svd_results = add_config_attributes(svd_results, parsed_config)
-        svd_results = space_coord_to_level_lat_lon(svd_results)
+        U, s, V, coords, X, X_mean, X_std = _device_pipeline(ds, parsed_config, comm)
+        svd_results = None
+        if comm.rank == 0:
+            svd_results = combine_svd_results(U, s, V, coords, X=X, X_mean=X_mean, X_std=X_std)
+            svd_results = add_config_attributes(svd_results, parsed_config)
+            svd_results = space_coord_to_level_lat_lon(svd_results)
     except Exception as e:
         msg = f"Error in the SVD on ERA5 process: {e}"
         log_and_print(logger, msg, "error")
         raise Exception(msg) from e
+    finally:
+        if created:
+            import torch.distributed as dist
 
-    if write_to_netcdf:
+            dist.destroy_process_group()
+
+    if write_to_netcdf and svd_results is not None:
         try:
             log_and_print(logger, "Writing SVD results to NetCDF...")
             io_netcdf.to_netcdf(svd_results, parsed_config["save_path"])

@@ -470,6 +470,81 @@ class Reader:
         shape, dt, _ = self.variables[name]
         return self._read(name, (stop - start,) + shape[1:], dt, (start, stop), out)
 
+    def read_box(self, name: str, starts, counts, out: np.ndarray | None = None) -> np.ndarray:
+        """The hyperslab ``[starts[i], starts[i] + counts[i])`` of a numeric variable -- a time slab
+        of ONE rank's latitude band when the rows (space points) are sharded over GPUs.  Contiguous
+        native datasets are read as parallel preads of the runs the box consists of, anything
+        else through H5Sselect_hyperslab."""
+        shape, dt, _ = self.variables[name]
+        starts, counts = [int(v) for v in starts], [int(v) for v in counts]
+        if len(starts) != len(shape) or len(counts) != len(shape) or isinstance(dt, str) or dt.kind == "S":
+            raise ValueError(f"read_box: {name} needs {len(shape)} starts / counts of a numeric variable")
+        for a, c, full in zip(starts, counts, shape):
+            if a < 0 or c < 0 or a + c > full:
+                raise IndexError(f"read_box: [{a}, {a + c}) outside a dimension of {full} in {name}")
+        if out is not None:
+            if out.shape != tuple(counts) or out.dtype != dt or not out.flags.c_contiguous:
+                raise ValueError("read_box: out must be C-contiguous with the box's shape and dtype")
+        else:
+            out = np.empty(counts, dtype=dt)
+        if out.size == 0:
+            return out
+        if name in self.raw_offset and RAW_READ_THREADS > 0:
+            return self._read_box_raw(name, shape, dt, starts, counts, out)
+        lib = self.lib
+        did = lib.H5Dopen2(self.fid, name.encode(), _H5P_DEFAULT)
+        fsp = lib.H5Dget_space(did)
+        msp = lib.H5Screate_simple(len(counts), _dims(*counts), None)
+        try:
+            lib.H5Sselect_hyperslab(fsp, _H5S_SELECT_SET, _dims(*starts), None, _dims(*counts), None)
+            if lib.H5Dread(did, _h5type(lib, dt), msp, fsp, _H5P_DEFAULT, out.ctypes.data_as(C.c_void_p)) < 0:
+                raise OSError(f"H5Dread failed for {name}")
+        finally:
+            lib.H5Sclose(fsp)
+            lib.H5Sclose(msp)
+            lib.H5Dclose(did)
+        return out
+
+    def _read_box_raw(self, name, shape, dt, starts, counts, out):
+        from concurrent.futures import ThreadPoolExecutor
+
+        # the box is contiguous in the file from dimension j on (every later dimension is whole)
+        j = len(shape) - 1
+        while j > 0 and starts[j] == 0 and counts[j] == shape[j]:
+            j -= 1
+        inner = int(np.prod(shape[j + 1:], dtype=np.int64)) * dt.itemsize     # bytes per index of dim j
+        run = counts[j] * inner
+        strides = [int(np.prod(shape[i + 1:], dtype=np.int64)) * dt.itemsize for i in range(len(shape))]
+        base = self.raw_offset[name] + sum(a * st for a, st in zip(starts, strides))
+        outer = counts[:j]
+        nruns = int(np.prod(outer, dtype=np.int64)) if outer else 1
+        if self._fd < 0:
+            self._fd = os.open(self.path, os.O_RDONLY)
+        mv = memoryview(out).cast("B")
+
+        def rd(lo, hi):
+            for r in range(lo, hi):
+                off, rem = base, r
+                for i in range(j - 1, -1, -1):
+                    rem, idx = divmod(rem, outer[i])
+                    off += idx * strides[i]
+                a, b = r * run, (r + 1) * run
+                while a < b:
+                    got = os.preadv(self._fd, [mv[a:b]], off + (a - r * run))
+                    if got <= 0:
+                        raise OSError(f"short read of {name} at byte {off}")
+                    a += got
+
+        per = max(1, (8 << 20) // max(run, 1))
+        tasks = [(lo, min(nruns, lo + per)) for lo in range(0, nruns, per)]
+        if len(tasks) == 1:
+            rd(*tasks[0])
+        else:
+            if self._pool is None:
+                self._pool = ThreadPoolExecutor(max_workers=RAW_READ_THREADS)
+            list(self._pool.map(lambda t: rd(*t), tasks))
+        return out
+
     def _read_raw(self, name, shape, dt, rng, out_buf):
         """Rows [rng) of a contiguous native dataset by parallel preads into ``out`` (the HDF5
         library reads through one thread: ~9 GB/s from the page cache; 8 preading threads

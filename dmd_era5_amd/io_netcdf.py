@@ -232,7 +232,8 @@ def _read_hdf5(path: str) -> Dataset:
         nbytes = int(np.prod(shape)) * (dt.itemsize if hasattr(dt, "itemsize") else 8)
         if nbytes > LAZY_BYTES and not isinstance(dt, str) and len(shape) >= 2:
             vals = LazyArray(shape, dt, lambda n=name: r.read(n),
-                             lambda a, b, out=None, n=name: r.read_slab(n, a, b, out))
+                             lambda a, b, out=None, n=name: r.read_slab(n, a, b, out),
+                             lambda st, ct, out=None, n=name: r.read_box(n, st, ct, out))
         else:
             vals = r.read(name)
         raw[name] = (dims, vals, attrs)

@@ -59,9 +59,19 @@ class LazyArray:
     """A file-backed array (like xarray's lazily opened variables): shape / dtype are known,
     the data are read on first use, or in slabs along the first axis by the streaming ingest."""
 
-    def __init__(self, shape, dtype, read_all, read_slab):
+    def __init__(self, shape, dtype, read_all, read_slab, read_box=None):
         self.shape, self.dtype, self.ndim = tuple(shape), np.dtype(dtype), len(shape)
         self._read_all, self.read_slab = read_all, read_slab
+        # read_box(starts, counts, out=None): a hyperslab (one rank's latitude band of a time slab)
+        self.read_box = read_box or self._box_from_slab
+
+    def _box_from_slab(self, starts, counts, out=None):
+        slab = self.read_slab(starts[0], starts[0] + counts[0])
+        box = slab[(slice(None),) + tuple(slice(a, a + c) for a, c in zip(starts[1:], counts[1:]))]
+        if out is None:
+            return np.ascontiguousarray(box)
+        out[...] = box
+        return out
 
     def __array__(self, dtype=None, copy=None):
         a = self._read_all()

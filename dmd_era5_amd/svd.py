@@ -67,6 +67,12 @@ class Comm:
         last-bit or sign difference between devices would make the U shards inconsistent."""
         return tensors if len(tensors) != 1 else tensors[0]
 
+    def gather_to_root(self, t: torch.Tensor) -> list[torch.Tensor] | None:
+        """Every rank's tensor (shapes may differ in any dimension) as a list of HOST tensors on
+        rank 0, None elsewhere: the result assembly for the NetCDF write -- U, the row means
+        and, if asked for, X leave the devices only here."""
+        return [t.cpu()]
+
 
 class TorchDistComm(Comm):
     """torch.distributed communicator: backend "nccl" is RCCL over xGMI on ROCm;
@@ -97,6 +103,31 @@ class TorchDistComm(Comm):
             for t in tensors:
                 self._dist.broadcast(t, src=0, group=self._group)
         return tensors if len(tensors) != 1 else tensors[0]
+
+    def gather_to_root(self, t: torch.Tensor) -> list[torch.Tensor] | None:
+        if self.world_size == 1:
+            return [t.cpu()]
+        dist = self._dist
+        # gloo moves host memory, RCCL device memory: stage accordingly
+        on_host = dist.get_backend(self._group) == "gloo"
+        t = t.contiguous()
+        if t.dim() > 8:
+            raise ValueError("gather_to_root: at most 8 dimensions")
+        dims = torch.full((9,), -1, dtype=torch.int64, device="cpu" if on_host else t.device)
+        dims[0] = t.dim()
+        dims[1:1 + t.dim()] = torch.tensor(t.shape, dtype=torch.int64)
+        shapes = [tuple(int(v) for v in d[1:1 + int(d[0])].tolist()) for d in self.allgather(dims)]
+        if self.rank != 0:
+            if t.numel():
+                dist.send(t.cpu() if on_host else t, dst=0, group=self._group)
+            return None
+        out = [t.cpu()]
+        for r in range(1, self.world_size):
+            buf = torch.empty(shapes[r], dtype=t.dtype, device="cpu" if on_host else t.device)
+            if buf.numel():
+                dist.recv(buf, src=r, group=self._group)
+            out.append(buf.cpu())
+        return out
 
 
 @dataclass

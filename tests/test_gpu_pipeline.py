@@ -218,3 +218,70 @@ def test_create_mock_era5_svd_and_combine_like_the_reference_tests():
     dx = combine_svd_results(U, s, V, coords, X=X)
     assert sorted(dx.data_vars.keys()) == ["U", "V", "X", "s"]
     assert dx["U"].shape[0] == dx["X"].shape[0] and dx["V"].shape[1] == dx["X"].shape[1]
+
+
+def test_main_sharded_over_two_ranks(svd_base_config, tmp_path, monkeypatch):
+    """``main`` under torch.distributed.run, one process per rank, the space
+    points sharded by latitude band -- here two ranks sharing the one GPU of the box over gloo
+    (the driver's multi-GPU runs use RCCL).  Rank 0's result file must hold the same
+    decomposition, in the same row order, as a single-process run on the same slice."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+
+    from dmd_era5_amd import io_netcdf
+    from dmd_era5_amd.era5_svd import main
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    cfg = dict(svd_base_config, start_datetime="2019-01-01T00", end_datetime="2019-01-03T00",
+               variables="temperature,v_component_of_wind", levels="850,1000", svd_type="standard",
+               mean_center=True, scale=True, delay_embedding=2, n_components=3, save_data_matrix=True)
+    from dmd_era5_amd.config_parser import config_parser
+    from dmd_era5_amd.create_mock_data import add_download_attributes, create_mock_era5
+
+    roots = {}
+    for tag in ("one", "two"):
+        roots[tag] = tmp_path / tag
+        roots[tag].mkdir()
+        monkeypatch.setenv("DMD_ERA5_ROOT", str(roots[tag]))
+        p = config_parser(cfg, "era5-svd")
+        ds = create_mock_era5(cfg["start_datetime"], cfg["end_datetime"], p["variables"], p["levels"], seed=8)
+        # three planted space-time patterns above the mock's white noise, so that the leading
+        # singular triplets are separated and comparable between the two runs
+        t = np.arange(ds["temperature"].shape[0], dtype=np.float64)[:, None, None, None]
+        lat = np.radians(ds.coords["latitude"].values)[None, None, :, None]
+        lon = np.radians(ds.coords["longitude"].values)[None, None, None, :]
+        for v, name in enumerate(ds.data_vars):
+            f = ds[name].values
+            f = f + 60 * np.sin(2 * np.pi * t / 24) * np.cos(lat) * np.cos(lon + v)
+            f = f + 35 * np.cos(2 * np.pi * t / 11) * np.sin(2 * lat) * np.sin(2 * lon)
+            f = f + 20 * (t / 49.0) ** 2 * np.cos(3 * lon) * np.ones_like(lat)
+            ds[name].values = f.astype(np.float32)
+        io_netcdf.to_netcdf(add_download_attributes(ds, p), p["era5_slice_path"])
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, DMD_ERA5_ROOT=str(roots["two"]), DMDX_DIST_BACKEND="gloo", DMDX_DEVICE="0",
+               DMDX_TEST_CONFIG=json.dumps(cfg))
+    run = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port),
+                          os.path.join(here, "dist_main_worker.py")],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0, run.stdout[-3000:] + run.stderr[-3000:]
+    assert "latitude rows 0:18" in run.stdout and "latitude rows 18:36" in run.stdout
+    two = io_netcdf.open_dataset(p["save_path"])
+
+    monkeypatch.setenv("DMD_ERA5_ROOT", str(roots["one"]))
+    one, _, _ = main(cfg, write_to_netcdf=False)
+    for name in ("U", "s", "V", "X", "X_mean", "X_std"):
+        assert two[name].shape == one[name].shape, name
+    assert np.array_equal(two["X"].values, one["X"].values)                # same rows, same order
+    assert np.array_equal(two["X_mean"].values, one["X_mean"].values)
+    for c in ("latitude", "longitude", "level", "original_variable", "delay"):
+        assert np.array_equal(two.coords[c].values, one.coords[c].values), c
+    assert np.allclose(two["s"].values, one["s"].values, rtol=1e-5)
+    rec2 = (two["U"].values.astype(np.float64) * two["s"].values) @ two["V"].values
+    rec1 = (one["U"].values.astype(np.float64) * one["s"].values) @ one["V"].values
+    assert np.linalg.norm(rec2 - rec1) <= 1e-3 * np.linalg.norm(rec1)

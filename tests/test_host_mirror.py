@@ -321,6 +321,41 @@ def test_hdf5_contiguous_datasets_are_read_by_parallel_preads(tmp_path, monkeypa
             r.read_slab("a", 0, 5, np.empty((5, 3, 90, 180), dtype=np.float64))
 
 
+def test_hdf5_read_box_is_a_hyperslab_on_both_read_paths(tmp_path, monkeypatch):
+    """One rank's share of a time slab (a latitude band of every level) = a hyperslab: the
+    pread runs and H5Sselect_hyperslab must both return the numpy slice."""
+    from dmd_era5_amd import hdf5_lite
+    from dmd_era5_amd.labeled import LazyArray
+
+    if not hdf5_lite.available():
+        pytest.skip("libhdf5 not found")
+    rs = np.random.RandomState(1)
+    a = rs.standard_normal((30, 3, 45, 64)).astype(np.float32)
+    b = rs.standard_normal((9, 700, 700)).astype(np.float64)          # runs of 3.9 MB: several tasks
+    path = str(tmp_path / "box.nc")
+    with hdf5_lite.Writer(path) as w:
+        w.dataset("a", a, ("time", "level", "latitude", "longitude"))
+        w.dataset("b", b, ("t2", "y", "x"))
+    boxes_a = [((4, 0, 10, 0), (11, 3, 17, 64)), ((0, 1, 0, 5), (30, 2, 45, 7)), ((29, 2, 44, 63), (1, 1, 1, 1)),
+               ((0, 0, 0, 0), (30, 3, 45, 64)), ((3, 0, 0, 0), (0, 3, 45, 64))]
+    with hdf5_lite.Reader(path) as r:
+        for threads in (hdf5_lite.RAW_READ_THREADS or 8, 0):
+            monkeypatch.setattr(hdf5_lite, "RAW_READ_THREADS", threads)
+            for st, ct in boxes_a:
+                ref = a[tuple(slice(x, x + c) for x, c in zip(st, ct))]
+                assert np.array_equal(r.read_box("a", st, ct), ref)
+            assert np.array_equal(r.read_box("b", (1, 100, 0), (8, 555, 700)), b[1:9, 100:655])
+            out = np.empty((2, 3, 5, 64), dtype=np.float32)
+            assert r.read_box("a", (7, 0, 40, 0), (2, 3, 5, 64), out) is out and np.array_equal(out, a[7:9, :, 40:45])
+            with pytest.raises(IndexError):
+                r.read_box("a", (0, 0, 40, 0), (1, 3, 6, 64))
+            with pytest.raises(ValueError):
+                r.read_box("a", (0, 0, 0), (1, 1, 1))
+    # arrays that only know time slabs get the box by slicing the slab
+    la = LazyArray(a.shape, a.dtype, lambda: a, lambda t0, t1, out=None: a[t0:t1])
+    assert np.array_equal(la.read_box((4, 0, 10, 0), (11, 3, 17, 64)), a[4:15, :, 10:27])
+
+
 def test_hdf5_label_coordinates_with_millions_of_strings(tmp_path):
     """`original_variable (space)`-type coordinates: run-length factorised on write, converted by
     the C helper on read (ASCII fast path, UTF-8 path, no-run fallback)."""

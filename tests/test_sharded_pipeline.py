@@ -1,0 +1,131 @@
+"""SURVEY.md 8(e), result assembly: the device pipeline of ``main`` with the space points sharded by
+latitude band over two ranks (gloo, CPU kernel double) must hand rank 0 the same U / s / V /
+X / X_mean / X_std, in the reference's global row order, as the single-rank pipeline -- with the
+variables read lazily from an HDF5 slice (each rank reads only its hyperslabs)."""
+import os
+import socket
+import sys
+from datetime import timedelta
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from kernel_double import CpuKernelDouble
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _cfg(svd_type, d, center, scale, levels):
+    return {"delay_embedding": d, "mean_center": center, "scale": scale, "levels": levels,
+            "delta_time": timedelta(hours=1), "n_components": 3, "svd_type": svd_type,
+            "save_data_matrix": True, "random_state": 0}
+
+
+def _open(path):
+    from dmd_era5_amd import io_netcdf
+
+    io_netcdf.LAZY_BYTES = 1000            # every variable file-backed
+    os.environ["DMDX_NETCDF_BACKEND"] = "hdf5"
+    return io_netcdf.open_dataset(path)
+
+
+def _run(path, cfg, comm):
+    from dmd_era5_amd import era5_svd
+
+    era5_svd.SLAB_BYTES = 11 * 3 * 36 * 72 * 4          # several slabs per variable
+    ds = _open(path)
+    return era5_svd._device_pipeline(ds, cfg, comm, kern=CpuKernelDouble(), device=torch.device("cpu"))
+
+
+def _worker(rank, world, port, path, cfg, q):
+    for p in (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__)))):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+
+    from dmd_era5_amd import svd as dsvd
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        U, s, V, coords, X, Xm, Xs = _run(path, cfg, dsvd.TorchDistComm())
+        if rank == 0:
+            q.put((U, s, V, X.values, None if Xm is None else Xm.values, None if Xs is None else Xs.values,
+                   np.asarray(coords["delay"].values)))
+        else:
+            assert U is None and X is None and Xm is None and coords is None
+            q.put(None)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("svd_type,d,center,scale,levels,world", [
+    ("standard", 2, True, True, [850, 1000], 2),
+    ("randomized", 1, True, False, None, 2),
+    ("standard", 3, False, False, [500], 3),          # un-centred temperature: the mean-deflation path
+])
+def test_latitude_band_shards_assemble_to_the_single_rank_result(tmp_path, svd_type, d, center, scale, levels, world):
+    from dmd_era5_amd import hdf5_lite, io_netcdf
+    from dmd_era5_amd.create_mock_data import create_mock_era5
+
+    if not hdf5_lite.available():
+        pytest.skip("libhdf5 not found")
+    ds = create_mock_era5("2019-01-01", "2019-01-03", ["temperature", "u_component_of_wind"], [1000, 850, 500],
+                          seed=6, dtype=np.float32)
+    # three planted space-time patterns well above the mock's noise: separated singular values, so
+    # that vectors are comparable one by one (the mock itself is noise with a flat spectrum)
+    t = np.arange(49, dtype=np.float64)
+    lat = np.radians(ds.coords["latitude"].values)[None, None, :, None]
+    lon = np.radians(ds.coords["longitude"].values)[None, None, None, :]
+    lev = np.array([1.0, 0.7, 0.4])[None, :, None, None]
+    for v, name in enumerate(ds.data_vars):
+        f = ds[name].values.astype(np.float64)
+        f += 60 * np.sin(2 * np.pi * t / 24)[:, None, None, None] * np.cos(lat) * np.cos(lon + v) * lev
+        f += 35 * np.cos(2 * np.pi * t / 11)[:, None, None, None] * np.sin(2 * lat) * np.sin(2 * lon) * lev[:, ::-1]
+        f += 20 * ((t / 49.0) ** 2)[:, None, None, None] * np.cos(3 * lon) * np.ones_like(lat) * lev
+        ds[name].values = f.astype(np.float32)
+    path = str(tmp_path / "slice.nc")
+    os.environ["DMDX_NETCDF_BACKEND"] = "hdf5"
+    io_netcdf.to_netcdf(ds, path)
+    cfg = _cfg(svd_type, d, center, scale, levels)
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, path, cfg, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    U, s, V, X, Xm, Xs, delay = next(g for g in got if g is not None)
+
+    from dmd_era5_amd import svd as dsvd
+
+    U1, s1, V1, coords1, X1, Xm1, Xs1 = _run(path, cfg, dsvd.Comm())
+    nlev = len(levels) if levels else 3
+    assert U.shape == U1.shape == (d * 2 * nlev * 36 * 72, 3)
+    assert np.array_equal(X, X1.values)                                   # same rows in the same order
+    assert np.array_equal(delay, np.asarray(coords1["delay"].values))
+    if center and d > 1:
+        assert np.allclose(Xm, Xm1.values, rtol=0, atol=1e-4 * np.abs(Xm1.values).max())
+        if scale:
+            assert np.allclose(Xs, Xs1.values, rtol=1e-5)
+    else:
+        assert Xm is None and Xm1 is None
+    assert np.allclose(s, s1, rtol=1e-5)
+    gap = np.min(np.abs(np.diff(s1))) / s1[0]
+    assert gap > 0.01
+    tol = 5e-6 / gap
+    for j in range(3):                                                    # vectors up to rounding (sign is fixed by svd_flip)
+        assert abs(np.dot(U[:, j], U1[:, j])) > 1 - tol
+        assert abs(np.dot(V[j], V1[j])) > 1 - tol
+    rec = (U * s) @ V
+    assert np.linalg.norm(rec - (U1 * s1) @ V1) <= 2e-4 * np.linalg.norm(rec)

@@ -24,7 +24,7 @@ def _free_port():
 def _cfg(svd_type, d, center, scale, levels):
     return {"delay_embedding": d, "mean_center": center, "scale": scale, "levels": levels,
             "delta_time": timedelta(hours=1), "n_components": 3, "svd_type": svd_type,
-            "save_data_matrix": True, "random_state": 0}
+            "save_data_matrix": True, "svd_seed": 0}
 
 
 def _open(path):

@@ -353,6 +353,18 @@ def _device_pipeline(ds: Dataset, parsed_config: dict, comm=None, kern=None, dev
     nlev, nlat, nlon = len(levels), len(lats), len(lons)
     band = lat_band(nlat, comm.rank, comm.world_size) if comm.world_size > 1 else None
 
+    if device.type == "cuda":
+        # X must be resident: say so before the allocator does, and say what would fit
+        rows = len(names) * nlev * ((band[1] - band[0]) if band else nlat) * nlon
+        need = 4 * rows * len(take) + (12 << 30)          # X + Gram workspace / U / small dense pieces
+        free = torch.cuda.mem_get_info(device)[0]
+        if need > free:
+            ranks = -(-4 * len(names) * nlev * nlat * nlon * len(take) // max(free - (12 << 30), 1 << 30))
+            raise MemoryError(
+                f"the snapshot matrix of this rank ({rows} x {len(take)} fp32 = {4 * rows * len(take) / 1e9:.1f} GB) "
+                f"does not fit the {free / 1e9:.1f} GB of free HBM; shard the space points over more GPUs: "
+                f"python -m torch.distributed.run --nproc-per-node N -m dmd_era5_amd.era5_svd with N >= {max(ranks, comm.world_size + 1)}")
+
     t0 = _time.perf_counter()
     blocks, stats, total = [], {"mean": [], "std": []}, 0
     for name in names:

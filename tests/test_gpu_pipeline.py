@@ -285,3 +285,20 @@ def test_main_sharded_over_two_ranks(svd_base_config, tmp_path, monkeypatch):
     rec2 = (two["U"].values.astype(np.float64) * two["s"].values) @ two["V"].values
     rec1 = (one["U"].values.astype(np.float64) * one["s"].values) @ one["V"].values
     assert np.linalg.norm(rec2 - rec1) <= 1e-3 * np.linalg.norm(rec1)
+
+
+def test_slice_larger_than_hbm_is_refused_with_advice(svd_base_config, project_root, monkeypatch):
+    """X must be resident in HBM: a slice that does not fit is refused before the upload, with the
+    number of ranks that would hold it."""
+    import torch
+
+    from dmd_era5_amd.era5_svd import main
+
+    cfg = dict(svd_base_config, start_datetime="2019-01-01T00", end_datetime="2019-01-02T00", svd_type="standard")
+    _write_slice(cfg, seed=1, dtype=np.float32)
+    monkeypatch.setattr(torch.cuda, "mem_get_info", lambda *a, **k: (13 << 30, 288 << 30))
+    main(cfg)                                                     # 60 KB of X next to 1 GiB of headroom: fine
+    monkeypatch.setattr(torch.cuda, "mem_get_info", lambda *a, **k: (12 << 30, 288 << 30))
+    monkeypatch.setenv("DMD_ERA5_ROOT", str(project_root))
+    with pytest.raises(Exception, match="Error in the SVD on ERA5 process: .*does not fit.*torch.distributed.run"):
+        main(dict(cfg, n_components=9))                            # (another result file: no cache hit)

@@ -44,3 +44,22 @@ if os.environ.get("DMDX_PROFILE_MAIN"):
     main(cfg, write_to_netcdf=True)
     pr.disable()
     pstats.Stats(pr).sort_stats("cumulative").print_stats(35)
+# one rank's share when the space points are sharded over 8 GPUs: the latitude band read as hyperslabs
+import torch
+from dmd_era5_amd import era5_svd
+from dmd_era5_amd.kernels import default_kernels
+ds = io_netcdf.open_dataset(p["era5_slice_path"])
+lvl, _, take, _ = era5_svd.plan_selection(ds, None, p["delta_time"])
+for rank in (0, 3):
+    band = era5_svd.lat_band(nlat, rank, 8)
+    for rep in range(2):
+        stats = {"mean": [], "std": []}
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        blocks, m_v, nbytes = era5_svd._upload_variable(ds["temperature"], lvl, take, torch.device("cuda", 0), default_kernels(),
+                                                       True, False, stats, band)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        print(f"band {band} of rank {rank}/8, rep {rep}: {nbytes/1e9:.2f} GB in {dt*1e3:.0f} ms = {nbytes/dt/1e9:.1f} GB/s", flush=True)
+    ref = torch.from_numpy(np.ascontiguousarray(ds["temperature"].lazy.read_slab(5, 6)[0, 0, band[0]:band[1]].reshape(-1))).cuda()
+    got = torch.cat(blocks, dim=1)[5] + torch.cat(stats["mean"])
+    print("   row check:", float((got - ref).abs().max()))
+    del blocks

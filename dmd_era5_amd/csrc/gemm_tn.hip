@@ -620,6 +620,9 @@ __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(
 
 struct Plan {
   int tm;  // tile rows: 128, or 96 / 64 when that cuts the row padding of a non-SYRK product
+  int syrk;  // triangle of tiles + mirror; a Gram of <= 96 columns runs as one 64- / 96-row tile of the
+             // plain product X^T X instead (both triangles computed: half / three quarters of the MFMA
+             // work of the 128 x 128 tile, no mirror pass)
   int ntr, ntc, ntiles, nsplit, chunks_total, chunks_per_split;
   size_t ws_bytes;
 };
@@ -628,6 +631,9 @@ struct Plan {
 Plan make_plan(int64_t K, int64_t nrow, int64_t ncol, int syrk, int share = 1) {
   Plan pl;
   pl.tm = BT;
+  const int gram = syrk;
+  if (syrk && nrow <= 96) syrk = 0;
+  pl.syrk = syrk;
   if (!syrk) {  // fewest padded rows; ties go to the taller tile (fewer re-reads of the B panels)
     int64_t best = (nrow + BT - 1) / BT * BT;
     for (int tm : {96, 64}) {
@@ -650,7 +656,7 @@ Plan make_plan(int64_t K, int64_t nrow, int64_t ncol, int syrk, int share = 1) {
   // operands are re-read from L2 anyway (big SYRK); few-tile products and the HBM-streaming
   // X^T Y / Q^T X products (every X panel is read once) want few, long units
   // (cfg2 randomized: K3 97.6 ms at 20 rounds, 91.5 at 4..8; l x l Grams 12.5 -> 7.6 ms at 2).
-  int64_t rounds = syrk ? (pl.ntiles >= 64 ? 20 : 2) : 6;
+  int64_t rounds = gram ? (pl.ntiles >= 64 ? 20 : 2) : 6;
   if (const char* e = getenv("DMDX_TN_ROUNDS")) rounds = atoll(e) > 0 ? atoll(e) : rounds;
   const int64_t per_split = (int64_t)pl.ntiles * share;
   int64_t want = (rounds * 512 + per_split - 1) / per_split;
@@ -678,7 +684,7 @@ int run_tn(const float* A, int64_t lda, const float* B, int64_t ldb, int64_t K, 
   TnParams p;
   p.A = A; p.B = B; p.lda = lda; p.ldb = ldb; p.K = K;
   p.nrow = (int)nrow; p.ncol = (int)ncol;
-  p.ntr = pl.ntr; p.ntc = pl.ntc; p.ntiles = pl.ntiles; p.syrk = syrk;
+  p.ntr = pl.ntr; p.ntc = pl.ntc; p.ntiles = pl.ntiles; p.syrk = pl.syrk;
   p.nsplit = pl.nsplit; p.chunks_total = pl.chunks_total;
   p.chunks_per_split = pl.chunks_per_split;
   p.P = reinterpret_cast<double*>(ws);
@@ -716,7 +722,7 @@ int run_tn(const float* A, int64_t lda, const float* B, int64_t ldb, int64_t K, 
     hipLaunchKernelGGL(gemm_tn_partial_kernel<false>, grid, dim3(NTH), 0, stream, p);
   DMDX_LAUNCH_CHECK();
   hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3(pl.ntiles * (pl.tm / 32) * 4), dim3(256), 0, stream, p.P,
-                     pl.nsplit, pl.ntiles, pl.ntr, pl.ntc, syrk, (int)nrow, (int)ncol, D64, ld64, D32, ld32,
+                     pl.nsplit, pl.ntiles, pl.ntr, pl.ntc, pl.syrk, (int)nrow, (int)ncol, D64, ld64, D32, ld32,
                      accumulate, pl.tm);
   DMDX_LAUNCH_CHECK();
   return 0;
@@ -776,7 +782,7 @@ int run_batch(const float* const* A, const int64_t* lda, const float* const* B, 
     bt.nblocks = nb;
     p.nrow = (int)nrow;
     p.ncol = (int)ncol;
-    p.ntr = pl.ntr; p.ntc = pl.ntc; p.ntiles = pl.ntiles; p.syrk = syrk;
+    p.ntr = pl.ntr; p.ntc = pl.ntc; p.ntiles = pl.ntiles; p.syrk = pl.syrk;
     p.nsplit = slabs;
     p.P = reinterpret_cast<double*>(ws);
     const dim3 grid((unsigned)units);
@@ -792,7 +798,7 @@ int run_batch(const float* const* A, const int64_t* lda, const float* const* B, 
     }
     DMDX_LAUNCH_CHECK();
     hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3(pl.ntiles * (pl.tm / 32) * 4), dim3(256), 0, stream, p.P, slabs,
-                       pl.ntiles, pl.ntr, pl.ntc, syrk, (int)nrow, (int)ncol, D64, ld64, D32, ld32,
+                       pl.ntiles, pl.ntr, pl.ntc, pl.syrk, (int)nrow, (int)ncol, D64, ld64, D32, ld32,
                        (accumulate || j0 > 0) ? 1 : 0, pl.tm);
     DMDX_LAUNCH_CHECK();
   }

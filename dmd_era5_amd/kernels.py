@@ -200,17 +200,26 @@ class HipKernels:
         Wp[:, :n] = Wt
         return Wp[:, :n]
 
-    def skinny(self, Xt: torch.Tensor, Wt: torch.Tensor) -> torch.Tensor:
-        """Y = X W.  Xt: (n, m), Wt: (l, n) fp32 -> Yt: (l, m) fp32."""
+    def skinny(self, Xt: torch.Tensor, Wt: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+        """Y = X W.  Xt: (n, m), Wt: (l, n) fp32 -> Yt: (l, m) fp32.
+
+        ``out``: an (l, m) fp32 view to write into (inner stride 1, any row stride >= m) -- a
+        column slice of the (l, M) result of all row blocks, so that no concatenation follows."""
         m, n, ldx = _check_mat(Xt, torch.float32, "skinny X")
         nw, l, ldw = _check_mat(Wt, torch.float32, "skinny W")
         if nw != n:
             raise _lib.DmdxError(f"skinny: W has {nw} rows, X has {n} columns")
         Wt = self.pitch(Wt)
         ldw = _check_mat(Wt, torch.float32, "skinny W")[2]
-        Yt = torch.empty((l, m), dtype=torch.float32, device=Xt.device)
+        if out is not None:
+            mo, lo, ldy = _check_mat(out, torch.float32, "skinny out")
+            if (mo, lo) != (m, l) or out.device != Xt.device:
+                raise _lib.DmdxError(f"skinny: out must be ({l}, {m}) on {Xt.device}, got {tuple(out.shape)}")
+            Yt = out
+        else:
+            Yt, ldy = torch.empty((l, m), dtype=torch.float32, device=Xt.device), m
         rc = self._timed("skinny", (m, n, l), lambda: self._lib.dmdx_gemm_nn_skinny_f32(
-            _ptr(Xt), m, n, ldx, _ptr(Wt), ldw, l, _ptr(Yt), m, self._stream()
+            _ptr(Xt), m, n, ldx, _ptr(Wt), ldw, l, _ptr(Yt), ldy, self._stream()
         ))
         _lib.check(rc, "dmdx_gemm_nn_skinny_f32")
         return Yt

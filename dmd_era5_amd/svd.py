@@ -343,6 +343,25 @@ def _gemm_tn_blocks(Ablocks, Bblocks, kern, comm: Comm) -> torch.Tensor:
     return comm.allreduce_sum_(C)
 
 
+def _project_blocks(kern, Xblocks, Wt: torch.Tensor, d: int):
+    """[X_b W for every row block] -> (blocks, whole).  Without delay embedding the per-block
+    results are written straight into column slices of ONE (l, M) tensor (``whole``; the blocks
+    are views of it), so that assembling U is not a second copy of it -- at cfg4 that copy was a
+    13 GB allocation next to 227 GB of X, which made the caching allocator hand cached segments
+    back to the driver (350 ms).  With d > 1 the rows of a block interleave with the other
+    blocks' (order k_delay*m + s) and ``whole`` is None."""
+    if d != 1 or len(Xblocks) == 1:
+        return [kern.skinny(X, Wt) for X in Xblocks], None
+    M = sum(int(X.shape[1]) for X in Xblocks)
+    whole = torch.empty((Wt.shape[0], M), dtype=torch.float32, device=Xblocks[0].device)
+    views, off = [], 0
+    for X in Xblocks:
+        mb = int(X.shape[1])
+        views.append(kern.skinny(X, Wt, out=whole[:, off:off + mb]))
+        off += mb
+    return views, whole
+
+
 def _assemble_rows(Ublocks, d: int) -> torch.Tensor:
     """Concatenate per-block results (k, d*mb_b) into (k, d*m) in the reference's
     embedded row order k_delay*m + s (slice_tools.py:207-211)."""
@@ -596,11 +615,11 @@ def svd_snapshots(Xt, n_components: int, delay: int = 1, oversample: int | None 
             inv_s = torch.where(ok, 1.0 / torch.where(ok, s, torch.ones_like(s)), torch.zeros_like(s))
             Rm = (s0[:, None] * Z) * inv_s[None, :]                   # (l, k): U = U' R
             Rt = _pitched(kern, Rm.T.contiguous().to(torch.float32))
-            Ub = [kern.skinny(U, Rt) for U in Up]                     # (k, d*mb)
+            Ub, whole = _project_blocks(kern, Up, Rt, delay)          # (k, d*mb)
             Vh = (V @ Z).T.contiguous()
         else:
             s = s0[:k]
-            Ub = [U[:k] for U in Up]
+            Ub, whole = [U[:k] for U in Up], None
             Vh = V[:, :k].T.contiguous()
     finally:
         if mus is not None:
@@ -608,7 +627,7 @@ def svd_snapshots(Xt, n_components: int, delay: int = 1, oversample: int | None 
                 B += mu                                              # un-centre: the caller's X is intact again
     if flip_sign:
         Ub, Vh = _sign_flip(Ub, Vh, comm, kern)
-    Ut = _assemble_rows(Ub, delay)
+    Ut = whole if whole is not None else _assemble_rows(Ub, delay)
     if timings:
         t4 = _sync_time(dev)
         info.update(t_gram=t1 - t0, t_eig=t2 - t1, t_project=t3 - t2, t_refine=t4 - t3,
@@ -655,7 +674,11 @@ def _cholqr(Yb, comm: Comm, kern, passes: int = 1):
             todo += 1
         Rinv = torch.linalg.solve_triangular(L.T, eye, upper=True)  # R = L^T
         Rt = _pitched(kern, comm.broadcast_(Rinv.T.contiguous().to(torch.float32)))
-        Yb = [kern.skinny(Y, Rt) for Y in Yb]
+        # block by block, dropping each input as soon as its output exists: the peak stays at one
+        # m x l matrix + one block instead of two matrices (13.7 GB each at cfg4, next to 227 GB of X)
+        # (the caller's list is overwritten in place -- it is consumed by this function)
+        for i in range(len(Yb)):
+            Yb[i] = kern.skinny(Yb[i], Rt)
     return Yb
 
 
@@ -737,12 +760,12 @@ def svd_randomized(Xt, n_components: int, delay: int = 1, n_oversamples: int = 1
     Uhat, s, Vh = Uhat.contiguous(), s.contiguous(), Vh.contiguous()
     comm.broadcast_(Uhat, s, Vh)
     Uk = _pitched(kern, Uhat[:, :k].T.contiguous().to(torch.float32))
-    Ub = [kern.skinny(Q, Uk) for Q in Qmb]       # U = Q Uhat
+    Ub, whole = _project_blocks(kern, Qmb, Uk, delay)   # U = Q Uhat
     s = s[:k]
     Vh = Vh[:k].contiguous()
     if flip_sign:
         Ub, Vh = _sign_flip(Ub, Vh, comm, kern)
-    Ut = _assemble_rows(Ub, delay)
+    Ut = whole if whole is not None else _assemble_rows(Ub, delay)
     if timings:
         info["t_total"] = _sync_time(dev) - t0
     info.update(l=l, k=k, nd=nd, n_iter=n_it, normalizer=power_iteration_normalizer,

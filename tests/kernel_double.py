@@ -39,8 +39,12 @@ class CpuKernelDouble:
             Cm = self.gemm_tn(A, B) if Cm is None else self.gemm_tn(A, B, out=Cm)
         return Cm
 
-    def skinny(self, Xt, Wt):
-        return (Wt.to(torch.float64) @ Xt.to(torch.float64)).float()
+    def skinny(self, Xt, Wt, out=None):
+        Y = (Wt.to(torch.float64) @ Xt.to(torch.float64)).float()
+        if out is None:
+            return Y
+        out.copy_(Y)
+        return out
 
     def row_center_scale_(self, Xt, scale):
         mean = Xt.to(torch.float64).mean(dim=0).float()

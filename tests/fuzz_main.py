@@ -1,4 +1,5 @@
-"""Scratch: random [era5-svd] configurations through main() against the oracle pipeline
+"""Not collected by pytest (run by hand on the GPU box: python tests/fuzz_main.py [cases]).  Random
+[era5-svd] configurations through main() against the oracle pipeline
 (oracle.preprocess + numpy fp64 SVD) on seeded mock slices."""
 import os, sys, shutil, tempfile
 import numpy as np

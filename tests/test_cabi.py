@@ -58,9 +58,12 @@ def test_argument_errors_are_reported_without_a_gpu(lib):
 
 
 def test_workspace_queries(lib):
-    # 1 tile, >= 1 split; 128*128 doubles per partial tile
-    assert lib.dmdx_syrk_workspace_bytes(1000, 64) % (128 * 128 * 8) == 0
+    # 1 tile, >= 1 split; a Gram of <= 96 columns runs as one 64- / 96-row tile (64*128 / 96*128
+    # doubles per partial tile), wider ones as 128*128 tiles
+    assert lib.dmdx_syrk_workspace_bytes(1000, 64) % (64 * 128 * 8) == 0
     assert lib.dmdx_syrk_workspace_bytes(1000, 64) > 0
+    assert lib.dmdx_syrk_workspace_bytes(1000, 90) % (96 * 128 * 8) == 0
+    assert lib.dmdx_syrk_workspace_bytes(1000, 200) % (128 * 128 * 8) == 0
     big = lib.dmdx_syrk_workspace_bytes(129780, 8760)
     assert 0 < big < 8 << 30
     assert lib.dmdx_gemm_tn_workspace_bytes(100000, 8760, 70) > 0

@@ -131,6 +131,17 @@ def _free_port():
         return s.getsockname()[1]
 
 
+def _sharded_case(svd_type):
+    """(X, k): 'steep' has s_k / s_1 ~ 1e-5 on top of 1e-7 noise, which sends svd_snapshots through
+    its polish step (a K2 + K3 pass with its own all-reduces)."""
+    if svd_type == "steep":
+        rs = np.random.RandomState(5)
+        A = np.linalg.qr(rs.standard_normal((3000, 24)))[0] * (100 * 0.55 ** np.arange(24))
+        X = A @ np.linalg.qr(rs.standard_normal((96, 24)))[0].T + 1e-7 * rs.standard_normal((3000, 96))
+        return X.astype(np.float32), 20
+    return orc.lowrank_matrix(3000, 96, 40, 2), 10
+
+
 def _worker(rank, world, port, svd_type, q):
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import torch.distributed as dist
@@ -138,20 +149,20 @@ def _worker(rank, world, port, svd_type, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        X = orc.lowrank_matrix(3000, 96, 40, 2)
+        X, k = _sharded_case(svd_type)
         rows = np.array_split(np.arange(3000), world)[rank]
         comm = dsvd.TorchDistComm()
         Xt = _xt(X[rows])
-        if svd_type == "standard":
-            r = dsvd.svd_snapshots(Xt, 10, comm=comm, kern=K)
+        if svd_type in ("standard", "steep"):
+            r = dsvd.svd_snapshots(Xt, k, comm=comm, kern=K)
         else:
-            r = dsvd.svd_randomized(Xt, 10, random_state=0, comm=comm, kern=K)
-        q.put((rank, r.s.numpy(), r.Ut.numpy(), r.Vh.numpy()))
+            r = dsvd.svd_randomized(Xt, k, random_state=0, comm=comm, kern=K)
+        q.put((rank, r.s.numpy(), r.Ut.numpy(), r.Vh.numpy(), bool(r.info.get("polished"))))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("svd_type", ["standard", "randomized"])
+@pytest.mark.parametrize("svd_type", ["standard", "randomized", "steep"])
 def test_row_sharded_two_ranks_equal_single_rank(svd_type):
     world = 2
     ctx = mp.get_context("spawn")
@@ -164,13 +175,21 @@ def test_row_sharded_two_ranks_equal_single_rank(svd_type):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    X = orc.lowrank_matrix(3000, 96, 40, 2)
-    if svd_type == "standard":
-        ref = dsvd.svd_snapshots(_xt(X), 10, kern=K)
+    X, k = _sharded_case(svd_type)
+    if svd_type in ("standard", "steep"):
+        ref = dsvd.svd_snapshots(_xt(X), k, kern=K)
     else:
-        ref = dsvd.svd_randomized(_xt(X), 10, random_state=0, kern=K)
+        ref = dsvd.svd_randomized(_xt(X), k, random_state=0, kern=K)
     U = np.concatenate([o[2] for o in out], axis=1)            # shards are contiguous row ranges
     assert np.allclose(out[0][1], out[1][1])                   # s replicated
+    if svd_type == "steep":
+        assert out[0][4] and out[1][4] and ref.info.get("polished")
+        s64 = np.linalg.svd(X.astype(np.float64), compute_uv=False)[:k]
+        assert np.allclose(out[0][1], s64, rtol=0, atol=2e-6 * s64[0])
+        assert np.allclose(out[0][1], ref.s.numpy(), rtol=0, atol=1e-7 * s64[0])
+        good = s64 > 1e-4 * s64[0]                             # vectors above the fp32 noise of X itself
+        assert np.all(np.abs(np.sum(U * ref.Ut.numpy(), axis=1))[good] > 1 - 1e-5)
+        return
     assert np.allclose(out[0][1], ref.s.numpy(), rtol=1e-8)
     assert np.allclose(out[0][3], ref.Vh.numpy(), atol=1e-7)
     assert np.allclose(U, ref.Ut.numpy(), atol=1e-6)           # includes the global sign flip

@@ -10,12 +10,14 @@ from dmd_era5_amd import io_netcdf, hdf5_lite
 from dmd_era5_amd.config_parser import config_parser
 from dmd_era5_amd.era5_svd import main
 
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+end = str((np.datetime64("2019-01-01T00") + np.timedelta64(n - 1, "h")).astype("datetime64[h]"))
 cfg = {"source_path": "synthetic", "variables": "temperature", "levels": "1000",
        "svd_type": "standard", "delay_embedding": 2, "mean_center": True, "scale": False,
-       "start_datetime": "2019-01-01T00", "end_datetime": "2019-02-11T15", "delta_time": "1h",
+       "start_datetime": "2019-01-01T00", "end_datetime": end, "delta_time": "1h",
        "n_components": 20, "save_data_matrix": False}
 p = config_parser(cfg, "era5-svd")
-n, nlat, nlon = 1000, 721, 1440            # 1000 hourly 0.25-degree fields = 4.15 GB
+nlat, nlon = 721, 1440                     # n hourly 0.25-degree fields: 1000 = 4.15 GB
 os.makedirs(os.path.dirname(p["era5_slice_path"]), exist_ok=True)
 rs = np.random.RandomState(0)
 t0 = time.perf_counter()

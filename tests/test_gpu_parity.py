@@ -334,6 +334,21 @@ def test_cfg2_full_size_svd_properties(K):
     fro = sum(float((blocks[0][j0:j0 + 1024].double() ** 2).sum()) for j0 in range(0, n, 1024))
     assert abs(float(torch.trace(G)) / fro - 1.0) < 1e-6
 
+    # the randomized path (sklearn defaults: l = 60, 7 power iterations) on the same resident
+    # matrix: behind 15 applications of X the 60-column sketch has converged on the leading 50
+    # directions ((sigma_61 / sigma_50)^15 ~ 3e-8), so it must reproduce the decomposition above
+    rr = dsvd.svd_randomized(blocks, r, random_state=0, kern=K)
+    assert rr.Ut.shape == (r, m) and rr.Vh.shape == (r, n) and rr.info["n_iter"] == 7
+    assert float(((rr.s - s).abs() / s).max()) < 1e-5
+    assert float((rr.Vh @ rr.Vh.T - eye).abs().max()) < 1e-10
+    assert float(((rr.Vh * Vh).sum(dim=1).abs() - 1.0).abs().max()) < 1e-6      # same right vectors, one by one
+    UrU = torch.zeros((r, r), dtype=torch.float64, device="cuda")
+    r0 = 0
+    for B in blocks:
+        UrU += rr.Ut[:, r0:r0 + B.shape[1]].double() @ Ut[:, r0:r0 + B.shape[1]].double().T
+        r0 += B.shape[1]
+    assert float((UrU.diagonal() - 1.0).abs().max()) < 1e-5                       # same left vectors and signs
+
 
 # ---------------------------------------------------------------- K7 small eigensolver
 @pytest.mark.parametrize("n", [1, 2, 3, 17, 62, 77, 96])

@@ -189,6 +189,38 @@ def _eigh_desc(T: torch.Tensor, kern=None):
     return torch.flip(th, dims=(0,)), torch.flip(Z, dims=(1,))
 
 
+def _graded_eigh(s0: torch.Tensor, Mm: torch.Tensor, kern=None):
+    """Eigenpairs (descending) of T = S M S, S = diag(s0) spanning many decades, M = U'^T U' close
+    to the identity -- with RELATIVE accuracy for the small eigenvalues.  Up to the Jacobi kernel's
+    size (K7, relative rotation criterion) T is solved directly.  Beyond it the library solver
+    (syevd) is only accurate to eps * s_1^2 absolutely: at s_k / s_1 = 5e-7 (cfg3's rank 200 on
+    the rank-64 + noise matrix) that is 4e-4 of the small eigenvalues, and U came out orthonormal
+    to 1e-3 only.  There T = B^T B with B = L^T S, M = L L^T, and the SVD of the l x l matrix B
+    gives the same eigenvectors (its right singular vectors) with errors relative to s, not s^2."""
+    l = s0.numel()
+    T = s0[:, None] * Mm * s0[None, :]
+    T = 0.5 * (T + T.T)
+    if kern is not None and l <= getattr(kern, "eigh_small_max_n", 0):
+        return _eigh_desc(T, kern)
+    g = torch.nonzero(s0 > 0).squeeze(1)
+    lg = int(g.numel())
+    if lg == 0:
+        return _eigh_desc(T, kern)
+    Mg = Mm[g][:, g]
+    L, err = torch.linalg.cholesky_ex(0.5 * (Mg + Mg.T))
+    if int(err.item()) != 0 or not bool(torch.isfinite(L).all()):
+        return _eigh_desc(T, kern)
+    _, sig, Vbh = torch.linalg.svd(L.T * s0[g][None, :])
+    mu = torch.zeros(l, dtype=T.dtype, device=T.device)
+    mu[:lg] = sig * sig
+    Z = torch.zeros((l, l), dtype=T.dtype, device=T.device)
+    Z[g, :lg] = Vbh.T
+    if lg < l:   # directions dropped from S: eigenvalue 0, unit eigenvectors
+        rest = torch.nonzero(s0 <= 0).squeeze(1)
+        Z[rest, torch.arange(lg, l, device=T.device)] = 1.0
+    return mu, Z
+
+
 def top_eigh(G: torch.Tensor, l: int, method: str = "auto", tol: float = 1e-9,
              max_outer: int = 40, info: dict | None = None, kern=None):
     """Largest ``l`` eigenpairs of the symmetric PSD fp64 matrix ``G`` (n x n),
@@ -604,9 +636,7 @@ def svd_snapshots(Xt, n_components: int, delay: int = 1, oversample: int | None 
             # Rayleigh-Ritz in span(V): (XV)^T (XV) = S (U'^T U') S, graded by S so the
             # small singular values keep their relative accuracy.
             Mm = _gram_blocks(Up, kern, comm)                         # (l, l) fp64
-            T = s0[:, None] * Mm * s0[None, :]
-            T = 0.5 * (T + T.T)
-            mu_, Z = _eigh_desc(T, kern)
+            mu_, Z = _graded_eigh(s0, Mm, kern)
             mu_ = mu_[:k].contiguous()
             Z = Z[:, :k].contiguous()
             comm.broadcast_(mu_, Z)

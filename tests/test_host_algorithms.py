@@ -74,6 +74,36 @@ def test_top_eigh_flat_spectrum_goes_to_the_full_solver_early():
     assert torch.equal(lam_a, lam_f) and torch.equal(V_a, V_f)
 
 
+def test_graded_refinement_matrix_keeps_relative_accuracy_without_the_jacobi_kernel():
+    """T = S M S with s over 7 decades: beyond K7's size the eigenpairs come from the SVD of
+    L^T S (M = L L^T), accurate relative to EACH eigenvalue (a library eigh of T only promises
+    eps * s_1^2: rocSOLVER's syevd left U orthonormal to 1e-3 at cfg3's rank 200; host LAPACK
+    happens to do better on such matrices) -- checked against a 50-digit mpmath solution."""
+    mpmath = pytest.importorskip("mpmath")
+    rs = np.random.RandomState(7)
+    l = 36
+    E = rs.standard_normal((l, l)) * 1e-3
+    Mn = np.eye(l) + 0.5 * (E + E.T)
+    sn = np.logspace(0, -7, l)
+    mpmath.mp.dps = 50
+    Tm = mpmath.matrix(l, l)
+    for i in range(l):
+        for j in range(l):
+            Tm[i, j] = mpmath.mpf(float(sn[i])) * mpmath.mpf(float(Mn[i, j])) * mpmath.mpf(float(sn[j]))
+    exact = np.array(sorted((float(x) for x in mpmath.eigsy(Tm, eigvals_only=True)), reverse=True))
+    M, s0 = torch.from_numpy(Mn), torch.from_numpy(sn)
+    mu_s, Z_s = dsvd._graded_eigh(s0, M, None)               # no small-eigh provider: the SVD route
+    assert np.max(np.abs(mu_s.numpy() - exact) / exact) < 1e-9
+    T = s0[:, None] * M * s0[None, :]
+    assert float(((T @ Z_s - Z_s * mu_s).norm(dim=0) / mu_s).max()) < 1e-6     # residuals relative to EACH eigenvalue
+    # directions dropped from S come back as zero eigenvalues with unit eigenvectors
+    s1 = s0.clone()
+    s1[-3:] = 0.0
+    mu_z, Z_z = dsvd._graded_eigh(s1, M, None)
+    assert torch.all(mu_z[-3:] == 0) and torch.allclose(mu_z[:-3], dsvd._graded_eigh(s0[:-3], M[:-3, :-3], None)[0])
+    assert torch.allclose(Z_z.T @ Z_z, torch.eye(l, dtype=torch.float64), atol=1e-12)
+
+
 def test_randomized_same_omega_as_sklearn():
     g = np.load(os.path.join(GOLDEN, "lowrank_4096x192.npz"))
     X = orc.lowrank_matrix(4096, 192, 100, 0)

@@ -536,7 +536,7 @@ def test_differential_sweep_against_numpy(i, m, n, k, kind, typ):
     exact_type = typ == "standard" or kind in ("lowrank", "deficient")
     if exact_type:
         assert np.abs(s - sref[:kk]).max() <= 2e-5 * sref[0], (kind, typ, m, n, k)
-    live = s > 1e-4 * s[0]                                        # null directions carry no constraint
+    live = s > 1e-6 * s[0]                                        # directions below the fp32 resolution of X carry no constraint
     Ul, Vl = U[:, live].astype(np.float64), V[live].astype(np.float64)
     assert np.abs(Ul.T @ Ul - np.eye(live.sum())).max() < 5e-4
     assert np.abs(Vl @ Vl.T - np.eye(live.sum())).max() < 5e-4

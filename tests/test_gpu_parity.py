@@ -391,6 +391,42 @@ def test_cfg3_shard_full_size_svd_properties(K):
     assert float((err / s[0]).max()) < 1e-6
 
 
+@pytest.mark.parametrize("k", [50, 200])
+def test_cfg4_shape_randomized_properties(K, k):
+    """BASELINE config 4's shape at 1/8 of its rows: 1 946 700 x 3653 fp32 (28 GB; n % 4 != 0, so
+    the small operand of K2 is re-pitched), randomized SVD with oversample 20 and 2 power
+    iterations, k = 50 (l = 70: 96-row K3 tiles, 96-column Grams) and k = 200 (l = 220: two K2
+    column groups, 128-row tiles).  Properties: U^T U = I, V V^T = I, s non-increasing, and the
+    planted part of the spectrum equal to the method-of-snapshots result on the same matrix."""
+    import bench
+    from dmd_era5_amd import svd as dsvd
+
+    free, _ = torch.cuda.mem_get_info()
+    if free < 60 * 2**30:
+        pytest.skip("needs ~45 GB of HBM")
+    m, n = 15 * 721 * 1440 // 8, 3653
+    blocks = bench.make_snapshot_blocks(m, n, 99, torch.device("cuda"))
+    for B in blocks:
+        K.row_center_scale_(B, False)
+    rr = dsvd.svd_randomized(blocks, k, n_oversamples=20, n_iter=2, random_state=0, kern=K)
+    st = dsvd.svd_snapshots(blocks, 60, kern=K)
+    assert rr.Ut.shape == (k, m) and rr.Vh.shape == (k, n) and rr.info["l"] == k + 20
+    assert bool((rr.s[:-1] >= rr.s[1:]).all())
+    lead = min(k, 60)
+    # (sigma_{l+1} / sigma_j)^5 with sigma_{l+1} at the noise level: the leading values are exact to fp32
+    assert float(((rr.s[:lead] - st.s[:lead]).abs() / st.s[:lead]).max()) < (1e-5 if k == 200 else 2e-3)
+    assert float(((rr.s[:40] - st.s[:40]).abs() / st.s[:40]).max()) < 1e-5
+    eye = torch.eye(k, dtype=torch.float64, device="cuda")
+    assert float((rr.Vh @ rr.Vh.T - eye).abs().max()) < 1e-10
+    UtU = torch.zeros((k, k), dtype=torch.float64, device="cuda")
+    r0 = 0
+    for B in blocks:
+        Ub = rr.Ut[:, r0:r0 + B.shape[1]].double()
+        UtU += Ub @ Ub.T
+        r0 += B.shape[1]
+    assert float((UtU - eye).abs().max()) < 2e-5
+
+
 # ---------------------------------------------------------------- K7 small eigensolver
 @pytest.mark.parametrize("n", [1, 2, 3, 17, 62, 77, 96])
 def test_eigh_small_matches_lapack(K, n):

@@ -695,6 +695,8 @@ def _cholqr(Yb, comm: Comm, kern, passes: int = 1):
             # (the Gram of fp32 products can be indefinite by more than 1e-6 of its trace --
             # identical values accumulate their rounding coherently -- so the shift escalates)
             tr = torch.diagonal(G).sum()
+            if float(tr) == 0.0 and bool(torch.isfinite(G).all()):
+                return Yb      # Y is exactly zero (X = 0): nothing to orthonormalise, s comes out 0
             for rel in (1e-6, 3e-5, 1e-3, 3e-2):
                 L, err = torch.linalg.cholesky_ex(G + (rel * tr) * eye)
                 if int(err) == 0 and bool(torch.isfinite(torch.diagonal(L)).all()):

@@ -74,6 +74,20 @@ def test_top_eigh_flat_spectrum_goes_to_the_full_solver_early():
     assert torch.equal(lam_a, lam_f) and torch.equal(V_a, V_f)
 
 
+@pytest.mark.parametrize("shape", [(9, 2), (500, 30)])
+def test_all_zero_matrix_gives_zero_singular_values(shape):
+    """X = 0 (found by the sparse kind of the differential fuzz): s = 0, U = 0, V orthonormal, for
+    both types -- the range finder's CholeskyQR has nothing to factor and must not raise."""
+    m, n = shape
+    k = min(n, 5)
+    for fn in (dsvd.svd_snapshots, dsvd.svd_randomized):
+        kw = {"random_state": 0} if fn is dsvd.svd_randomized else {}
+        r = fn(torch.zeros((n, m)), k, kern=K, **kw)
+        assert r.s.shape == (k,) and float(r.s.abs().max()) == 0.0
+        assert float(r.Ut.abs().max()) == 0.0 and bool(torch.isfinite(r.Vh).all())
+        assert torch.allclose(r.Vh @ r.Vh.T, torch.eye(k, dtype=torch.float64), atol=1e-12)
+
+
 def test_graded_refinement_matrix_keeps_relative_accuracy_without_the_jacobi_kernel():
     """T = S M S with s over 7 decades: beyond K7's size the eigenpairs come from the SVD of
     L^T S (M = L L^T), accurate relative to EACH eigenvalue (a library eigh of T only promises

@@ -5,7 +5,7 @@ import os, sys, shutil, tempfile
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 24
-rs0 = np.random.RandomState(11)
+rs0 = np.random.RandomState(11 + int(os.environ.get("DMDX_FUZZ_SEED", "0")))
 ALLV = ["temperature", "u_component_of_wind", "v_component_of_wind"]
 ALLL = [1000, 925, 850, 500]
 bad = 0

@@ -378,7 +378,31 @@ def _device_pipeline(ds: Dataset, parsed_config: dict, comm=None, kern=None, dev
                           f"{len(blocks)} row blocks, centre/scale on device){shard}")
     k = parsed_config["n_components"]
     t0 = _time.perf_counter()
-    if parsed_config["svd_type"] == "standard":
+    rows_global = d * len(names) * nlev * nlat * nlon
+    if rows_global < len(take) - d + 1:
+        # WIDE problem (fewer space rows than snapshots: a coarse mock grid over a long period).
+        # sklearn transposes wide inputs (extmath.py:562-566) and LAPACK does not care; here the
+        # tall algorithms run on E^T -- the embedded matrix is small by definition (< n^2 floats),
+        # so it is materialised -- and the factors swap roles.
+        if comm.world_size > 1:
+            raise ValueError(f"{rows_global} space rows < {len(take) - d + 1} snapshots: a wide problem is small, "
+                             "run it as a single process (no torch.distributed)")
+        nd = len(take) - d + 1
+        Xall = torch.cat(blocks, dim=1)                                            # (n, M)
+        E = torch.cat([Xall[kd:kd + nd].T for kd in range(d)], dim=0).contiguous()  # (d M, nd): row kd*M + s
+        del Xall
+        log_and_print(logger, f"Performing {parsed_config['svd_type']} SVD...")
+        if parsed_config["svd_type"] == "standard":
+            rt = dsvd.svd_snapshots(E, k, flip_sign=False, kern=kern)
+        else:
+            rt = dsvd.svd_randomized(E, k, flip_sign=False, kern=kern, **_engine_opts(parsed_config))
+        Ut = rt.Vh.to(torch.float32)                   # (k, d M): left singular vectors of E
+        Vh = rt.Ut.to(torch.float64)                   # (k, nd)
+        big = Ut.abs().argmax(dim=1, keepdim=True)     # u-based sign convention (svd_flip)
+        sign = torch.where(Ut.gather(1, big) < 0, -1.0, 1.0)
+        res = dsvd.SvdResult(Ut=Ut * sign, s=rt.s, Vh=Vh * sign.to(torch.float64), info=dict(rt.info, wide=True))
+        log_and_print(logger, f"{parsed_config['svd_type'].capitalize()} SVD complete.")
+    elif parsed_config["svd_type"] == "standard":
         log_and_print(logger, "Performing standard SVD...")
         res = dsvd.svd_snapshots(blocks, k, delay=d, comm=comm, kern=kern)
         if res.info.get("mean_deflated"):

@@ -302,3 +302,36 @@ def test_slice_larger_than_hbm_is_refused_with_advice(svd_base_config, project_r
     monkeypatch.setenv("DMD_ERA5_ROOT", str(project_root))
     with pytest.raises(Exception, match="Error in the SVD on ERA5 process: .*does not fit.*torch.distributed.run"):
         main(dict(cfg, n_components=9))                            # (another result file: no cache hit)
+
+
+@pytest.mark.parametrize("svd_type", ["standard", "randomized"])
+def test_main_on_a_wide_problem(svd_base_config, project_root, svd_type):
+    """Fewer space rows than snapshots (the 5-degree mock grid over 113 days of hourly data: 2592 x
+    2712): sklearn transposes such inputs, LAPACK does not care; the device pipeline runs the tall
+    algorithms on the transposed matrix and swaps the factors."""
+    from dmd_era5_amd import io_netcdf
+    from dmd_era5_amd.config_parser import config_parser
+    from dmd_era5_amd.create_mock_data import add_download_attributes, create_mock_era5
+    from dmd_era5_amd.era5_svd import main
+
+    cfg = dict(svd_base_config, start_datetime="2019-01-01T00", end_datetime="2019-04-23T23", svd_type=svd_type,
+               mean_center=True, scale=False, delay_embedding=1, n_components=3, save_data_matrix=True, svd_seed=0)
+    p = config_parser(cfg, "era5-svd")
+    ds = create_mock_era5(cfg["start_datetime"], cfg["end_datetime"], p["variables"], p["levels"], seed=12, dtype=np.float32)
+    t = np.arange(ds["temperature"].shape[0], dtype=np.float64)[:, None, None, None]
+    lat = np.radians(ds.coords["latitude"].values)[None, None, :, None]
+    lon = np.radians(ds.coords["longitude"].values)[None, None, None, :]
+    f = ds["temperature"].values.astype(np.float64)
+    f = f + 60 * np.sin(2 * np.pi * t / 24) * np.cos(lat) * np.cos(lon) + 35 * np.cos(2 * np.pi * t / 11) * np.sin(2 * lat) * np.sin(2 * lon)
+    f = f + 20 * (t / len(t)) ** 2 * np.cos(3 * lon) * np.ones_like(lat)
+    ds["temperature"].values = f.astype(np.float32)
+    io_netcdf.to_netcdf(add_download_attributes(ds, p), p["era5_slice_path"])
+    res, _, _ = main(cfg, write_to_netcdf=True)
+    X = res["X"].values.astype(np.float64)
+    assert X.shape == (2592, 2712) and res["U"].shape == (2592, 3) and res["V"].shape == (3, 2712)
+    U, s, V = (res[k].values.astype(np.float64) for k in ("U", "s", "V"))
+    sref = np.linalg.svd(X, compute_uv=False)[:3]
+    assert np.allclose(s, sref, rtol=1e-5 if svd_type == "standard" else 1e-4)
+    assert np.abs(U.T @ U - np.eye(3)).max() < 1e-5 and np.abs(V @ V.T - np.eye(3)).max() < 1e-5
+    assert np.max(np.linalg.norm(X.T @ U - V.T * s, axis=0) / s) < (1e-5 if svd_type == "standard" else 1e-3)
+    assert np.all(U[np.abs(U).argmax(axis=0), np.arange(3)] > 0)              # u-based sign convention

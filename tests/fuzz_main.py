@@ -23,9 +23,13 @@ for i in range(N):
     step = int(rs0.choice([1, 1, 3, 6])); d = int(rs0.choice([1, 2, 3])); center = bool(rs0.rand() < 0.7)
     scale = bool(center and rs0.rand() < 0.4); typ = "standard" if rs0.rand() < 0.7 else "randomized"
     days = int(rs0.randint(2, 5)); k = int(rs0.randint(2, 7)); dtype = np.float32 if rs0.rand() < 0.7 else np.float64
+    end = f"2019-01-0{1 + days}T00"
+    if rs0.rand() < 0.15:   # a WIDE problem: one field on the 5-degree grid over ~4 months of hourly data
+        vs, file_levels, want_levels, step, d, dtype = vs[:1], file_levels[:1], file_levels[:1], 1, 1, np.float32
+        end = f"2019-0{int(rs0.randint(4, 6))}-{int(rs0.randint(10, 28))}T00"
     cfg = {"source_path": "synthetic", "variables": ",".join(vs), "levels": ",".join(map(str, want_levels)),
            "svd_type": typ, "delay_embedding": d, "mean_center": center, "scale": scale,
-           "start_datetime": "2019-01-01T00", "end_datetime": f"2019-01-0{1 + days}T00", "delta_time": f"{step}h",
+           "start_datetime": "2019-01-01T00", "end_datetime": end, "delta_time": f"{step}h",
            "n_components": k, "save_data_matrix": True, "svd_seed": 0}
     wcfg = dict(cfg, delta_time="1h", levels=",".join(map(str, file_levels)))
     try:

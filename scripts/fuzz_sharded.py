@@ -45,7 +45,7 @@ if __name__ == "__main__":
     from dmd_era5_amd import io_netcdf, svd as dsvd
     from dmd_era5_amd.create_mock_data import create_mock_era5
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 12
-    rs = np.random.RandomState(2024)
+    rs = np.random.RandomState(2024 + int(os.environ.get("DMDX_FUZZ_SEED", "0")))
     tmp = tempfile.mkdtemp(prefix="dmdx_fuzz_sharded_")
     os.environ["DMDX_NETCDF_BACKEND"] = "hdf5"
     bad = 0

@@ -353,33 +353,93 @@ def _device_pipeline(ds: Dataset, parsed_config: dict, comm=None, kern=None, dev
     nlev, nlat, nlon = len(levels), len(lats), len(lons)
     band = lat_band(nlat, comm.rank, comm.world_size) if comm.world_size > 1 else None
 
-    if device.type == "cuda":
-        # X must be resident: say so before the allocator does, and say what would fit
+    k = parsed_config["n_components"]
+    rows_global = d * len(names) * nlev * nlat * nlon
+    wide = rows_global < len(take) - d + 1
+    shard = f" (rank {comm.rank} of {comm.world_size}: latitude rows {band[0]}:{band[1]})" if band else ""
+    stream_bytes = int(os.environ.get("DMDX_STREAM_BYTES", "0"))      # > 0 forces the streaming path (tests)
+    if device.type == "cuda" and not stream_bytes:
+        # X should be resident: find out before the allocator does
         rows = len(names) * nlev * ((band[1] - band[0]) if band else nlat) * nlon
         need = 4 * rows * len(take) + (12 << 30)          # X + Gram workspace / U / small dense pieces
         free = torch.cuda.mem_get_info(device)[0]
         if need > free:
-            ranks = -(-4 * len(names) * nlev * nlat * nlon * len(take) // max(free - (12 << 30), 1 << 30))
-            raise MemoryError(
-                f"the snapshot matrix of this rank ({rows} x {len(take)} fp32 = {4 * rows * len(take) / 1e9:.1f} GB) "
-                f"does not fit the {free / 1e9:.1f} GB of free HBM; shard the space points over more GPUs: "
-                f"python -m torch.distributed.run --nproc-per-node N -m dmd_era5_amd.era5_svd with N >= {max(ranks, comm.world_size + 1)}")
+            if parsed_config["svd_type"] == "standard" and center and not parsed_config["save_data_matrix"] and not wide:
+                stream_bytes = max(1 << 30, min(free // 3, 32 << 30))
+            else:
+                ranks = -(-4 * len(names) * nlev * nlat * nlon * len(take) // max(free - (12 << 30), 1 << 30))
+                raise MemoryError(
+                    f"the snapshot matrix of this rank ({rows} x {len(take)} fp32 = {4 * rows * len(take) / 1e9:.1f} GB) "
+                    f"does not fit the {free / 1e9:.1f} GB of free HBM; shard the space points over more GPUs: "
+                    f"python -m torch.distributed.run --nproc-per-node N -m dmd_era5_amd.era5_svd with N >= "
+                    f"{max(ranks, comm.world_size + 1)} (svd_type = standard with mean_center and without "
+                    "save_data_matrix streams such a slice from the file in two passes instead)")
 
-    t0 = _time.perf_counter()
-    blocks, stats, total = [], {"mean": [], "std": []}, 0
-    for name in names:
-        vb, _, nbytes = _upload_variable(ds[name], level_idx, take, device, kern, center, scale, stats, band)
-        blocks.extend(vb)
-        total += nbytes
-    sync()
-    dt = _time.perf_counter() - t0
-    shard = f" (rank {comm.rank} of {comm.world_size}: latitude rows {band[0]}:{band[1]})" if band else ""
-    log_and_print(logger, f"Ingest: {total / 1e9:.3f} GB to HBM in {dt:.2f} s ({total / 1e9 / max(dt, 1e-9):.2f} GB/s, "
-                          f"{len(blocks)} row blocks, centre/scale on device){shard}")
-    k = parsed_config["n_components"]
-    t0 = _time.perf_counter()
-    rows_global = d * len(names) * nlev * nlat * nlon
-    if rows_global < len(take) - d + 1:
+    blocks = []
+    if stream_bytes:
+        # X does not fit: the Gram is accumulated and the projection made while latitude sub-bands of
+        # the variables pass through the HBM, twice (svd.svd_snapshots_streaming)
+        if parsed_config["svd_type"] != "standard" or not center or parsed_config["save_data_matrix"] or wide:
+            raise ValueError("the streaming path covers svd_type = standard with mean_center and without save_data_matrix")
+        i0, i1 = band if band else (0, nlat)
+        h = max(1, stream_bytes // max(1, 4 * len(take) * nlev * nlon))       # latitude rows per piece
+        sub = [(j, min(i1, j + h)) for j in range(i0, i1, h)]
+        means, stds, moved = {}, {}, [0]
+
+        def pieces():
+            for vi, name in enumerate(names):
+                for j0, j1 in sub:
+                    st = {"mean": [], "std": []}
+                    vb, _, nbytes = _upload_variable(ds[name], level_idx, take, device, kern, center, scale, st, (j0, j1))
+                    means[(vi, j0)] = torch.cat(st["mean"])
+                    if scale:
+                        stds[(vi, j0)] = torch.cat(st["std"])
+                    moved[0] += nbytes
+                    yield vb
+
+        t0 = _time.perf_counter()
+        log_and_print(logger, f"Snapshot matrix larger than the HBM: streaming it in {len(names) * len(sub)} pieces of "
+                              f"<= {h} latitude rows, two passes{shard}")
+        log_and_print(logger, "Performing standard SVD...")
+        Ub, s_, Vh_, sinfo = dsvd.svd_snapshots_streaming(pieces, k, rows_global, delay=d, comm=comm, kern=kern)
+        if sinfo.get("warning"):
+            log_and_print(logger, "WARNING: " + sinfo["warning"])
+        kk = int(s_.numel())
+        Ul = torch.empty((kk, d, len(names), nlev, i1 - i0, nlon), dtype=torch.float32, device=device)
+        mean_l = torch.empty((len(names), nlev, i1 - i0, nlon), dtype=torch.float32, device=device)
+        std_l = torch.empty_like(mean_l) if scale else None
+        idx = 0
+        for vi in range(len(names)):
+            for j0, j1 in sub:      # a piece's rows: (level, its latitude rows, longitude), embedded as k_delay * m_piece + s
+                Ul[:, :, vi, :, j0 - i0:j1 - i0, :] = dsvd._assemble_rows(Ub[idx], d).reshape(kk, d, nlev, j1 - j0, nlon)
+                mean_l[vi, :, j0 - i0:j1 - i0, :] = means[(vi, j0)].reshape(nlev, j1 - j0, nlon)
+                if scale:
+                    std_l[vi, :, j0 - i0:j1 - i0, :] = stds[(vi, j0)].reshape(nlev, j1 - j0, nlon)
+                Ub[idx] = None
+                idx += 1
+        res = dsvd.SvdResult(Ut=Ul.reshape(kk, -1), s=s_, Vh=Vh_, info=sinfo)
+        stats = {"mean": [mean_l.reshape(-1)], "std": [std_l.reshape(-1)] if scale else []}
+        total = moved[0] // 2
+        sync()
+        dt = _time.perf_counter() - t0
+        log_and_print(logger, "Standard SVD complete.")
+        log_and_print(logger, f"Ingest + SVD (streamed twice): {dt:.2f} s ({2 * total / 1e9 / max(dt, 1e-9):.1f} GB/s of file data)")
+        t0 = _time.perf_counter()
+    else:
+        t0 = _time.perf_counter()
+        stats, total = {"mean": [], "std": []}, 0
+        for name in names:
+            vb, _, nbytes = _upload_variable(ds[name], level_idx, take, device, kern, center, scale, stats, band)
+            blocks.extend(vb)
+            total += nbytes
+        sync()
+        dt = _time.perf_counter() - t0
+        log_and_print(logger, f"Ingest: {total / 1e9:.3f} GB to HBM in {dt:.2f} s ({total / 1e9 / max(dt, 1e-9):.2f} GB/s, "
+                              f"{len(blocks)} row blocks, centre/scale on device){shard}")
+        t0 = _time.perf_counter()
+    if stream_bytes:
+        pass          # res, stats are ready
+    elif wide:
         # WIDE problem (fewer space rows than snapshots: a coarse mock grid over a long period).
         # sklearn transposes wide inputs (extmath.py:562-566) and LAPACK does not care; here the
         # tall algorithms run on E^T -- the embedded matrix is small by definition (< n^2 floats),
@@ -416,7 +476,8 @@ def _device_pipeline(ds: Dataset, parsed_config: dict, comm=None, kern=None, dev
         log_and_print(logger, "Randomized SVD complete.")
     sync()
     dt = _time.perf_counter() - t0
-    log_and_print(logger, f"SVD stage: {dt:.3f} s ({total / 1e9 / max(dt, 1e-9):.1f} GB/s of X)")
+    if not stream_bytes:
+        log_and_print(logger, f"SVD stage: {dt:.3f} s ({total / 1e9 / max(dt, 1e-9):.1f} GB/s of X)")
     src_dtype = ds[names[0]].dtype
     out_dtype = src_dtype if src_dtype in (np.float32, np.float64) else np.float64
 

@@ -42,6 +42,7 @@ __all__ = [
     "split_rows",
     "top_eigh",
     "svd_snapshots",
+    "svd_snapshots_streaming",
     "svd_randomized",
 ]
 
@@ -664,6 +665,73 @@ def svd_snapshots(Xt, n_components: int, delay: int = 1, oversample: int | None 
                     t_total=t4 - t0)
     info.update(l=l, k=k, nd=nd, row_blocks=len(blocks))
     return SvdResult(Ut=Ut, s=s, Vh=Vh, info=info)
+
+
+# ---------------------------------------------------------------------------
+# "standard", snapshot matrix larger than the HBM: two streaming passes
+# ---------------------------------------------------------------------------
+def svd_snapshots_streaming(pieces, n_components: int, rows_global: int, delay: int = 1,
+                            oversample: int | None = None, flip_sign: bool = True,
+                            comm: Comm | None = None, kern=None) -> tuple:
+    """Method of snapshots for an X that does not fit the HBM: ``pieces()`` is called twice and
+    yields, piece after piece, lists of (n, mb) row blocks (centred / scaled already, resident
+    only until the next piece is asked for).  Pass 1 accumulates the Gram, pass 2 projects:
+    only the m x l basis U' stays resident (l = k + max(8, k/4) columns against X's n).
+
+    Same arithmetic as :func:`svd_snapshots` on the concatenation of all pieces -- Gram in fp64
+    across blocks, top-l eigenpairs, U' = E V S^-1, Rayleigh-Ritz refinement, sign convention --
+    without the two refinements that need further passes over X: the exact deflation of a dominant
+    time mean (the caller centres the rows) and the polish step for spectra steeper than the Gram
+    resolves (``info["warning"]`` says so when it would have run).
+    ``rows_global``: rows of the embedded matrix over all ranks (caps k like numpy's slicing).
+    Returns (Ublocks, s, Vh, info): ``Ublocks[i]`` = list of (k, d*mb) tensors of piece i."""
+    kern = _kern(kern)
+    comm = comm or Comm()
+    info: dict = {"streaming": True}
+    G = None
+    for blocks in pieces():
+        G = kern.syrk_blocks(list(blocks), out=G) if (G is not None or len(blocks) > 1) else kern.syrk(blocks[0])
+    if G is None:
+        raise ValueError("svd_snapshots_streaming: no pieces")
+    comm.allreduce_sum_(G)
+    if not bool(torch.isfinite(torch.diagonal(G)).all()):
+        raise np.linalg.LinAlgError("SVD did not converge")
+    if delay > 1:
+        G = kern.delay_shift_sum(G, delay)
+    nd = G.shape[0]
+    k = min(n_components, nd, rows_global)
+    p = oversample if oversample is not None else max(8, k // 4)
+    l = min(nd, k + p)
+    lam, V = top_eigh(G, l, info=info, kern=kern)
+    comm.broadcast_(lam, V)
+    lam1 = lam[0].clamp_min(1e-300)
+    if float(lam[min(k, lam.numel()) - 1]) < 1e-7 * float(lam1):
+        info["warning"] = ("s_k < 3e-4 s_1: the Gram matrix of fp32 products resolves eigenvalues down to "
+                           "~1e-9 lambda_1 only, and the streaming path has no polish pass over X")
+    good = lam > lam1 * 1e-14
+    s0 = torch.sqrt(torch.where(good, lam, torch.ones_like(lam)))
+    inv_s0 = torch.where(good, 1.0 / s0, torch.zeros_like(s0))
+    s0 = torch.where(good, s0, torch.zeros_like(s0))
+    Wt = _pitched(kern, (V * inv_s0).T.contiguous().to(torch.float32))
+    Up = [[kern.skinny(embed_view(B, delay), Wt) for B in blocks] for blocks in pieces()]   # U' = E V S^-1
+    flat = [U for piece in Up for U in piece]
+    Mm = _gram_blocks(flat, kern, comm)
+    mu_, Z = _graded_eigh(s0, Mm, kern)
+    mu_, Z = mu_[:k].contiguous(), Z[:, :k].contiguous()
+    comm.broadcast_(mu_, Z)
+    s = torch.sqrt(mu_.clamp_min(0.0))
+    ok = s > s0[0] * 1e-7
+    inv_s = torch.where(ok, 1.0 / torch.where(ok, s, torch.ones_like(s)), torch.zeros_like(s))
+    Rt = _pitched(kern, ((s0[:, None] * Z) * inv_s[None, :]).T.contiguous().to(torch.float32))
+    Ub = []
+    for piece in Up:                      # U = U' R, piece by piece; U' of the piece is dropped right away
+        Ub.append([kern.skinny(U, Rt) for U in piece])
+        piece.clear()
+    Vh = (V @ Z).T.contiguous()
+    if flip_sign:
+        _, Vh = _sign_flip([U for piece in Ub for U in piece], Vh, comm, kern)
+    info.update(l=l, k=k, nd=nd)
+    return Ub, s, Vh, info
 
 
 # ---------------------------------------------------------------------------

@@ -335,3 +335,47 @@ def test_main_on_a_wide_problem(svd_base_config, project_root, svd_type):
     assert np.abs(U.T @ U - np.eye(3)).max() < 1e-5 and np.abs(V @ V.T - np.eye(3)).max() < 1e-5
     assert np.max(np.linalg.norm(X.T @ U - V.T * s, axis=0) / s) < (1e-5 if svd_type == "standard" else 1e-3)
     assert np.all(U[np.abs(U).argmax(axis=0), np.arange(3)] > 0)              # u-based sign convention
+
+
+@pytest.mark.parametrize("d,scale", [(1, False), (2, True)])
+def test_main_streams_a_slice_that_does_not_fit(svd_base_config, tmp_path, monkeypatch, d, scale):
+    """svd_type = standard with mean_center: a snapshot matrix larger than the free HBM is streamed
+    from the file in two passes (Gram, projection) instead of being refused.  Forced by a piece
+    budget of 5 latitude rows; the result must equal the resident run on the same slice."""
+    from dmd_era5_amd import io_netcdf
+    from dmd_era5_amd.config_parser import config_parser
+    from dmd_era5_amd.create_mock_data import add_download_attributes, create_mock_era5
+    from dmd_era5_amd.era5_svd import main
+
+    cfg = dict(svd_base_config, start_datetime="2019-01-01T00", end_datetime="2019-01-04T00",
+               variables="temperature,u_component_of_wind", levels="1000,500", svd_type="standard",
+               mean_center=True, scale=scale, delay_embedding=d, n_components=3, save_data_matrix=False)
+    out = {}
+    for tag in ("resident", "streamed"):
+        root = tmp_path / tag
+        root.mkdir()
+        monkeypatch.setenv("DMD_ERA5_ROOT", str(root))
+        monkeypatch.setenv("DMDX_NETCDF_BACKEND", "hdf5")
+        p = config_parser(cfg, "era5-svd")
+        ds = create_mock_era5(cfg["start_datetime"], cfg["end_datetime"], p["variables"], p["levels"], seed=31, dtype=np.float32)
+        t = np.arange(ds["temperature"].shape[0], dtype=np.float64)[:, None, None, None]
+        lat = np.radians(ds.coords["latitude"].values)[None, None, :, None]
+        lon = np.radians(ds.coords["longitude"].values)[None, None, None, :]
+        for v, name in enumerate(ds.data_vars):
+            f = ds[name].values.astype(np.float64)
+            f = f + 60 * np.sin(2 * np.pi * t / 24) * np.cos(lat) * np.cos(lon + v) + 35 * np.cos(2 * np.pi * t / 11) * np.sin(2 * lat) * np.sin(2 * lon)
+            f = f + 20 * (t / len(t)) ** 2 * np.cos(3 * lon) * np.ones_like(lat)
+            ds[name].values = f.astype(np.float32)
+        io_netcdf.to_netcdf(add_download_attributes(ds, p), p["era5_slice_path"])
+        if tag == "streamed":
+            monkeypatch.setenv("DMDX_STREAM_BYTES", str(5 * 4 * 73 * 2 * 72))
+        out[tag], _, _ = main(cfg, write_to_netcdf=True)
+        monkeypatch.delenv("DMDX_STREAM_BYTES", raising=False)
+    a, b = out["resident"], out["streamed"]
+    assert sorted(a.data_vars) == sorted(b.data_vars) and "X" not in b.data_vars
+    assert np.allclose(b["s"].values, a["s"].values, rtol=1e-6)
+    assert np.abs(b["U"].values - a["U"].values).max() < 1e-4 * np.abs(a["U"].values).max()
+    assert np.abs(b["V"].values - a["V"].values).max() < 1e-5
+    if d > 1:
+        assert np.array_equal(b["X_mean"].values, a["X_mean"].values)
+        assert np.allclose(b["X_std"].values, a["X_std"].values, rtol=1e-6)

@@ -35,15 +35,19 @@ def _open(path):
     return io_netcdf.open_dataset(path)
 
 
-def _run(path, cfg, comm):
+def _run(path, cfg, comm, stream_bytes=0):
     from dmd_era5_amd import era5_svd
 
     era5_svd.SLAB_BYTES = 11 * 3 * 36 * 72 * 4          # several slabs per variable
     ds = _open(path)
-    return era5_svd._device_pipeline(ds, cfg, comm, kern=CpuKernelDouble(), device=torch.device("cpu"))
+    os.environ["DMDX_STREAM_BYTES"] = str(int(stream_bytes))
+    try:
+        return era5_svd._device_pipeline(ds, cfg, comm, kern=CpuKernelDouble(), device=torch.device("cpu"))
+    finally:
+        os.environ.pop("DMDX_STREAM_BYTES", None)
 
 
-def _worker(rank, world, port, path, cfg, q):
+def _worker(rank, world, port, path, cfg, q, stream_bytes=0):
     for p in (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__)))):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -54,10 +58,10 @@ def _worker(rank, world, port, path, cfg, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        U, s, V, coords, X, Xm, Xs = _run(path, cfg, dsvd.TorchDistComm())
+        U, s, V, coords, X, Xm, Xs = _run(path, cfg, dsvd.TorchDistComm(), stream_bytes)
         if rank == 0:
-            q.put((U, s, V, X.values, None if Xm is None else Xm.values, None if Xs is None else Xs.values,
-                   np.asarray(coords["delay"].values)))
+            q.put((U, s, V, None if X is None else X.values, None if Xm is None else Xm.values,
+                   None if Xs is None else Xs.values, np.asarray(coords["delay"].values)))
         else:
             assert U is None and X is None and Xm is None and coords is None
             q.put(None)
@@ -129,3 +133,64 @@ def test_latitude_band_shards_assemble_to_the_single_rank_result(tmp_path, svd_t
         assert abs(np.dot(V[j], V1[j])) > 1 - tol
     rec = (U * s) @ V
     assert np.linalg.norm(rec - (U1 * s1) @ V1) <= 2e-4 * np.linalg.norm(rec)
+
+
+def _planted_slice(tmp_path):
+    from dmd_era5_amd import io_netcdf
+    from dmd_era5_amd.create_mock_data import create_mock_era5
+
+    ds = create_mock_era5("2019-01-01", "2019-01-03", ["temperature", "u_component_of_wind"], [1000, 850, 500],
+                          seed=16, dtype=np.float32)
+    t = np.arange(49, dtype=np.float64)[:, None, None, None]
+    lat = np.radians(ds.coords["latitude"].values)[None, None, :, None]
+    lon = np.radians(ds.coords["longitude"].values)[None, None, None, :]
+    for v, name in enumerate(ds.data_vars):
+        f = ds[name].values.astype(np.float64)
+        f = f + 60 * np.sin(2 * np.pi * t / 24) * np.cos(lat) * np.cos(lon + v) + 35 * np.cos(2 * np.pi * t / 11) * np.sin(2 * lat) * np.sin(2 * lon)
+        f = f + 20 * (t / 49.0) ** 2 * np.cos(3 * lon) * np.ones_like(lat)
+        ds[name].values = f.astype(np.float32)
+    path = str(tmp_path / "slice.nc")
+    os.environ["DMDX_NETCDF_BACKEND"] = "hdf5"
+    io_netcdf.to_netcdf(ds, path)
+    return path
+
+
+@pytest.mark.parametrize("d,scale,levels,world", [(1, False, None, 1), (2, True, [850, 1000], 1), (2, True, [500], 2)])
+def test_streaming_two_pass_pipeline_equals_the_resident_one(tmp_path, d, scale, levels, world):
+    """A snapshot matrix larger than the HBM is streamed from the file twice in latitude sub-bands
+    (Gram pass, projection pass; only the m x l basis stays resident).  Forced here by a piece
+    budget of 7 latitude rows: U, s, V, X_mean, X_std must equal the resident pipeline's -- as one
+    process and with the rows sharded over two ranks on top."""
+    from dmd_era5_amd import hdf5_lite
+    from dmd_era5_amd import svd as dsvd
+
+    if not hdf5_lite.available():
+        pytest.skip("libhdf5 not found")
+    path = _planted_slice(tmp_path)
+    cfg = dict(_cfg("standard", d, True, scale, levels), save_data_matrix=False)
+    nlev = len(levels) if levels else 3
+    budget = 7 * 4 * 49 * nlev * 72                       # 7 latitude rows per piece
+    if world == 1:
+        U, s, V, coords, X, Xm, Xs = _run(path, cfg, dsvd.Comm(), budget)
+        Xm, Xs = (None if a is None else a.values for a in (Xm, Xs))
+    else:
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_worker, args=(r, world, port, path, cfg, q, budget)) for r in range(world)]
+        for p in procs:
+            p.start()
+        got = [q.get(timeout=180) for _ in range(world)]
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        U, s, V, X, Xm, Xs, _ = next(g for g in got if g is not None)
+    U1, s1, V1, _, X1, Xm1, Xs1 = _run(path, cfg, dsvd.Comm())
+    assert X is None and X1 is None and U.shape == U1.shape == (d * 2 * nlev * 36 * 72, 3)
+    assert np.allclose(s, s1, rtol=1e-6)
+    if d > 1:
+        assert np.array_equal(Xm, Xm1.values)
+        assert (Xs is None) == (not scale) and (Xs is None or np.allclose(Xs, Xs1.values, rtol=1e-6))
+    for j in range(3):
+        assert abs(np.dot(U[:, j], U1[:, j])) > 1 - 1e-6 and abs(np.dot(V[j], V1[j])) > 1 - 1e-6
+    assert np.abs(U - U1).max() < 1e-4 * np.abs(U1).max()                # same rows in the same order, same signs

@@ -417,14 +417,15 @@ def _sign_flip(Ublocks, Vh: torch.Tensor, comm: Comm, kern):
     for Ut in Ublocks:
         idx = Ut.abs().argmax(dim=1, keepdim=True)
         vals.append(Ut.gather(1, idx).squeeze(1))
-    if comm.world_size > 1:
-        gathered = []
-        for v in vals:
-            gathered.extend(comm.allgather(v.contiguous()))
-        vals = gathered
-    allv = torch.stack(vals, dim=0)  # (blocks x world, k)
+    allv = torch.stack(vals, dim=0)  # (blocks, k)
     pick = allv.abs().argmax(dim=0, keepdim=True)
     val = allv.gather(0, pick).squeeze(0)
+    if comm.world_size > 1:
+        # ONE exchange per rank, whatever its number of row blocks (ranks may hold different numbers
+        # of blocks: bands of different height, streamed pieces)
+        allv = torch.stack(comm.allgather(val.contiguous()), dim=0)  # (world, k)
+        pick = allv.abs().argmax(dim=0, keepdim=True)
+        val = allv.gather(0, pick).squeeze(0)
     sign = torch.where(val < 0, -torch.ones_like(val), torch.ones_like(val))
     for Ut in Ublocks:
         kern.scale_columns_(Ut, sign.to(torch.float32))

@@ -197,6 +197,8 @@ def _worker(rank, world, port, svd_type, q):
         rows = np.array_split(np.arange(3000), world)[rank]
         comm = dsvd.TorchDistComm()
         Xt = _xt(X[rows])
+        if rank == 0:   # ranks need not hold the same number of row blocks (one exchange per rank, not per block)
+            Xt = [Xt[:, :400].contiguous(), Xt[:, 400:401].contiguous(), Xt[:, 401:].contiguous()]
         if svd_type in ("standard", "steep"):
             r = dsvd.svd_snapshots(Xt, k, comm=comm, kern=K)
         else:

@@ -363,7 +363,11 @@ def _device_pipeline(ds: Dataset, parsed_config: dict, comm=None, kern=None, dev
         rows = len(names) * nlev * ((band[1] - band[0]) if band else nlat) * nlon
         need = 4 * rows * len(take) + (12 << 30)          # X + Gram workspace / U / small dense pieces
         free = torch.cuda.mem_get_info(device)[0]
-        if need > free:
+        fits = need <= free
+        if comm.world_size > 1:   # one decision for all ranks: the resident and the streaming path exchange differently
+            flags = comm.allgather(torch.tensor([1 if fits else 0], dtype=torch.int64, device=device))
+            fits = all(int(f.item()) for f in flags)
+        if not fits:
             if parsed_config["svd_type"] == "standard" and center and not parsed_config["save_data_matrix"] and not wide:
                 stream_bytes = max(1 << 30, min(free // 3, 32 << 30))
             else:

@@ -44,6 +44,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <vector>
+
 #include "dmdx_common.h"
 
 namespace {
@@ -860,8 +862,30 @@ int dmdx_syrk_blocks_f32(const float* const* X, const int64_t* m, const int64_t*
                    workspace_bytes, (hipStream_t)stream);
 }
 
+// D rows beyond one 128-row tile (l > 128 columns of Y in Z = X^T Y): the full 128-row tiles in one
+// launch, the remaining rows in a second one with the tile height that pads least (64 / 96) -- when
+// that is less MFMA work than any uniform tile height (l = 220: 128 + 96 = 224 rows instead of
+// 256).  The second launch streams the big operand once more; these products are MFMA-bound by a
+// factor > 3 at such l, so the extra HBM pass is hidden.  Returns the split row, or 0.
+static int64_t tn_row_split(int64_t nrow) {
+  if (nrow <= BT) return 0;
+  const int64_t full = nrow / BT * BT, rem = nrow - full;
+  if (rem == 0 || rem > 96) return 0;
+  const int64_t rem_pad = rem <= 64 ? 64 : 96;
+  int64_t best = (nrow + BT - 1) / BT * BT;
+  for (int tm : {96, 64}) {
+    const int64_t padded = (nrow + tm - 1) / tm * tm;
+    if (padded < best) best = padded;
+  }
+  return full + rem_pad < best ? full : 0;
+}
+
 size_t dmdx_gemm_tn_workspace_bytes(int64_t K, int64_t na, int64_t nb) {
   if (K < 0 || na <= 0 || nb <= 0) return 0;
+  if (const int64_t cut = tn_row_split(nb)) {
+    const size_t w1 = make_plan(K, cut, na, 0).ws_bytes, w2 = make_plan(K, nb - cut, na, 0).ws_bytes;
+    return w1 > w2 ? w1 : w2;
+  }
   return make_plan(K, nb, na, 0).ws_bytes;
 }
 
@@ -876,6 +900,14 @@ int dmdx_gemm_tn_f32(const float* A, int64_t lda, const float* B, int64_t ldb, i
   DMDX_CHECK_ARG(lda < (1ll << 24) && ldb < (1ll << 24),
                  "gemm_tn: leading dimension >= 2^24 not supported (use row blocks)");
   // column-major C[a + b*ldc] == row-major D[b][a]: D rows <- B columns, D cols <- A columns
+  if (const int64_t cut = tn_row_split(nb)) {
+    const int rc = run_tn(B, ldb, A, lda, K, cut, na, 0, C64, ldc, C32, ldc32, accumulate, workspace,
+                          workspace_bytes, (hipStream_t)stream);
+    if (rc) return rc;
+    return run_tn(B + cut * ldb, ldb, A, lda, K, nb - cut, na, 0, C64 + cut * ldc, ldc,
+                  C32 ? C32 + cut * ldc32 : nullptr, ldc32, accumulate, workspace, workspace_bytes,
+                  (hipStream_t)stream);
+  }
   return run_tn(B, ldb, A, lda, K, nb, na, 0, C64, ldc, C32, ldc32, accumulate, workspace, workspace_bytes,
                 (hipStream_t)stream);
 }
@@ -886,7 +918,12 @@ size_t dmdx_gemm_tn_blocks_workspace_bytes(const int64_t* K, int nblocks, int64_
   for (int j0 = 0; j0 < nblocks; j0 += MAXB) {
     for (int j = j0; j < nblocks && j < j0 + MAXB; ++j)
       if (K[j] < 1) return 0;
-    const size_t g = batch_group_ws(K + j0, nblocks - j0 < MAXB ? nblocks - j0 : MAXB, nb, na, 0);
+    const int ng = nblocks - j0 < MAXB ? nblocks - j0 : MAXB;
+    size_t g = batch_group_ws(K + j0, ng, nb, na, 0);
+    if (const int64_t cut = tn_row_split(nb)) {
+      const size_t g1 = batch_group_ws(K + j0, ng, cut, na, 0), g2 = batch_group_ws(K + j0, ng, nb - cut, na, 0);
+      g = g1 > g2 ? g1 : g2;
+    }
     if (g > need) need = g;
   }
   return need;
@@ -902,6 +939,16 @@ int dmdx_gemm_tn_blocks_f32(const float* const* A, const int64_t* lda, const flo
   for (int j = 0; j < nblocks; ++j)
     DMDX_CHECK_ARG(A[j] && B[j] && K[j] >= 1 && lda[j] >= 1 && ldb[j] >= 1, "gemm_tn_blocks: bad block %d", j);
   // column-major C[a + b*ldc] == row-major D[b][a]: D rows <- B columns, D cols <- A columns
+  if (const int64_t cut = tn_row_split(nb)) {
+    const int rc = run_batch(B, ldb, A, lda, K, nblocks, cut, na, 0, C64, ldc, C32, ldc32, accumulate, workspace,
+                             workspace_bytes, (hipStream_t)stream);
+    if (rc) return rc;
+    std::vector<const float*> B2((size_t)nblocks);
+    for (int j = 0; j < nblocks; ++j) B2[j] = B[j] + cut * ldb[j];
+    return run_batch(B2.data(), ldb, A, lda, K, nblocks, nb - cut, na, 0, C64 + cut * ldc, ldc,
+                     C32 ? C32 + cut * ldc32 : nullptr, ldc32, accumulate, workspace, workspace_bytes,
+                     (hipStream_t)stream);
+  }
   return run_batch(B, ldb, A, lda, K, nblocks, nb, na, 0, C64, ldc, C32, ldc32, accumulate, workspace,
                    workspace_bytes, (hipStream_t)stream);
 }

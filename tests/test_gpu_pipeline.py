@@ -220,11 +220,14 @@ def test_create_mock_era5_svd_and_combine_like_the_reference_tests():
     assert dx["U"].shape[0] == dx["X"].shape[0] and dx["V"].shape[1] == dx["X"].shape[1]
 
 
-def test_main_sharded_over_two_ranks(svd_base_config, tmp_path, monkeypatch):
+@pytest.mark.parametrize("streamed", [False, True])
+def test_main_sharded_over_two_ranks(svd_base_config, tmp_path, monkeypatch, streamed):
     """``main`` under torch.distributed.run, one process per rank, the space
     points sharded by latitude band -- here two ranks sharing the one GPU of the box over gloo
     (the driver's multi-GPU runs use RCCL).  Rank 0's result file must hold the same
-    decomposition, in the same row order, as a single-process run on the same slice."""
+    decomposition, in the same row order, as a single-process run on the same slice.
+    ``streamed``: each rank additionally streams its band from the file in two passes (pieces of
+    4 latitude rows), as it would for a slice larger than the HBM."""
     import json
     import os
     import socket
@@ -237,7 +240,7 @@ def test_main_sharded_over_two_ranks(svd_base_config, tmp_path, monkeypatch):
     here = os.path.dirname(os.path.abspath(__file__))
     cfg = dict(svd_base_config, start_datetime="2019-01-01T00", end_datetime="2019-01-03T00",
                variables="temperature,v_component_of_wind", levels="850,1000", svd_type="standard",
-               mean_center=True, scale=True, delay_embedding=2, n_components=3, save_data_matrix=True)
+               mean_center=True, scale=True, delay_embedding=2, n_components=3, save_data_matrix=not streamed)
     from dmd_era5_amd.config_parser import config_parser
     from dmd_era5_amd.create_mock_data import add_download_attributes, create_mock_era5
 
@@ -265,6 +268,8 @@ def test_main_sharded_over_two_ranks(svd_base_config, tmp_path, monkeypatch):
         port = sk.getsockname()[1]
     env = dict(os.environ, DMD_ERA5_ROOT=str(roots["two"]), DMDX_DIST_BACKEND="gloo", DMDX_DEVICE="0",
                DMDX_TEST_CONFIG=json.dumps(cfg))
+    if streamed:
+        env["DMDX_STREAM_BYTES"] = str(4 * 4 * 49 * 2 * 72)
     run = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                           "--master-addr", "127.0.0.1", "--master-port", str(port),
                           os.path.join(here, "dist_main_worker.py")],
@@ -275,9 +280,13 @@ def test_main_sharded_over_two_ranks(svd_base_config, tmp_path, monkeypatch):
 
     monkeypatch.setenv("DMD_ERA5_ROOT", str(roots["one"]))
     one, _, _ = main(cfg, write_to_netcdf=False)
-    for name in ("U", "s", "V", "X", "X_mean", "X_std"):
+    for name in ("U", "s", "V", "X_mean", "X_std") + (() if streamed else ("X",)):
         assert two[name].shape == one[name].shape, name
-    assert np.array_equal(two["X"].values, one["X"].values)                # same rows, same order
+    if streamed:
+        assert "X" not in two.data_vars and "streaming it in" in run.stdout
+        assert np.abs(two["U"].values - one["U"].values).max() < 1e-4 * np.abs(one["U"].values).max()
+    else:
+        assert np.array_equal(two["X"].values, one["X"].values)            # same rows, same order
     assert np.array_equal(two["X_mean"].values, one["X_mean"].values)
     for c in ("latitude", "longitude", "level", "original_variable", "delay"):
         assert np.array_equal(two.coords[c].values, one.coords[c].values), c

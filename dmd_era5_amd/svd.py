@@ -227,7 +227,7 @@ def top_eigh(G: torch.Tensor, l: int, method: str = "auto", tol: float = 1e-9,
     """Largest ``l`` eigenpairs of the symmetric PSD fp64 matrix ``G`` (n x n),
     eigenvalues descending.
 
-    ``full``: torch.linalg.eigh.  ``krylov``: restarted block Krylov with
+    ``full``: torch.linalg.eigh.  ``krylov``: block power steps, then restarted block Krylov with
     Rayleigh-Ritz (only products G @ block, thin QRs and a (3b x 3b) eigh), run
     until every wanted pair has residual <= tol * lambda_1 (default 1e-9: the level of G's own
     rounding error -- its entries are sums of fp32 products --, i.e. the pairs returned are exact
@@ -236,8 +236,17 @@ def top_eigh(G: torch.Tensor, l: int, method: str = "auto", tol: float = 1e-9,
     """
     n = G.shape[0]
     l = min(l, n)
+    # auto (measured on the MI355X, l = 62: scripts/probe_eig_threshold.py): the block power steps
+    # cost 3-4 ms whatever n is and finish every steep spectrum; the library solver costs 9 / 17 /
+    # 23 / 36 ms at n = 384 / 768 / 1024 / 1536 and a Krylov sweep sequence ~19 ms whatever n is.
+    # So: power steps first unless the block would be most of the matrix, then the full solver up
+    # to n = 1024, Krylov sweeps above.
+    full_after_power = False
     if method == "auto":
-        method = "full" if (n <= 1536 or 4 * l >= n) else "krylov"
+        if n <= 256 or 4 * l >= n:
+            method = "full"
+        else:
+            method, full_after_power = "krylov", n <= 1024
     if method == "full":
         lam, V = torch.linalg.eigh(G)
         lam = torch.flip(lam[-l:], dims=(0,))
@@ -283,6 +292,8 @@ def top_eigh(G: torch.Tensor, l: int, method: str = "auto", tol: float = 1e-9,
         if res <= tol:
             return done(th, Qn, res, "power", it + 1)
         Q = Qn
+    if full_after_power:
+        return top_eigh(G, l, method="full", info=info, kern=kern)
 
     def orth_against(Y, P):
         """Orthonormal basis of the part of span(Y) outside span(P) (P orthonormal): block

@@ -172,10 +172,10 @@ __device__ unsigned long long dmdx_stamp[8];
 // DMA = false: everything register-staged with scalar loads (any alignment).
 // ABL: timing-only ablations for diagnosis (results are wrong when ABL != 0):
 //   1 no global->LDS staging, 2 no barrier, 8 no chain fold (none of them changes an address).  Selected by DMDX_TN_ABLATE.
-// SK ("skinny rows", 0 / 2 / 3): a (32 SK) x 128 output tile, the four waves side by side (each
-//   32 SK rows x 32 columns = SK x 1 MFMA blocks) -- for D with few rows (Z = X^T Y with l <= 64
-//   or 64 < l <= 96 columns of Y): half / three quarters of the MFMA work of a 128-row tile that
-//   would be padding for the rest.
+// SK ("skinny rows", 0 / 1 / 2 / 3): a (32 SK) x 128 output tile, the four waves side by side (each
+//   32 SK rows x 32 columns = SK x 1 MFMA blocks) -- for D with few rows (Z = X^T Y with l <= 32,
+//   <= 64 or <= 96 columns of Y): a quarter / half / three quarters of the MFMA work of a 128-row
+//   tile that would be padding for the rest.
 // One work unit: the K-range of `split` of the TM x 128 output tile at (row0, col0) (D rows <-
 // columns of A, D cols <- columns of B), written as fp64 into the partial tile Pt.
 // lds: 2 stages of (TM + 128) x 32 floats.
@@ -292,7 +292,7 @@ __device__ __forceinline__ void tn_unit(const TnParams& p, const int split, cons
 #define DMDX_COMMIT_ALL()                                                         \
   do {                                                                            \
     DMDX_COMMIT(0, 0);                                                            \
-    DMDX_COMMIT(1, 0);                                                            \
+    if constexpr (MI >= 2) DMDX_COMMIT(MI >= 2 ? 1 : 0, 0);                       \
     if constexpr (NI == 2) {                                                      \
       DMDX_COMMIT(0, NI - 1);                                                     \
       DMDX_COMMIT(1, NI - 1);                                                     \
@@ -344,6 +344,11 @@ __device__ __forceinline__ void tn_unit(const TnParams& p, const int split, cons
                "global_load_lds_dwordx4 %[a2], %[ap_] offset:2048"                                 \
                :: [la_] "s"(la), [ap_] "s"(ptr), [a0] "v"(o0), [a1] "v"(o1), [a2] "v"(o2)           \
                : "memory")
+#define DMDX_DMA_OP1(ptr, la, o0)                                                                  \
+  asm volatile("s_mov_b32 m0, %[la_]\n\ts_nop 0\n\t"                                               \
+               "global_load_lds_dwordx4 %[a0], %[ap_]"                                             \
+               :: [la_] "s"(la), [ap_] "s"(ptr), [a0] "v"(o0)                                       \
+               : "memory")
 #define DMDX_DMA_OP2(ptr, la, o0, o1)                                                              \
   asm volatile("s_mov_b32 m0, %[la_]\n\ts_nop 0\n\t"                                               \
                "global_load_lds_dwordx4 %[a0], %[ap_]\n\t"                                         \
@@ -354,7 +359,8 @@ __device__ __forceinline__ void tn_unit(const TnParams& p, const int split, cons
   do {                                                                                             \
     if constexpr (NPA == 4) DMDX_DMA_OP4(ap, la, aoffb[0], aoffb[1], aoffb[NPA - 2], aoffb[NPA - 1]); \
     else if constexpr (NPA == 3) DMDX_DMA_OP3(ap, la, aoffb[0], aoffb[1], aoffb[NPA - 1]);         \
-    else DMDX_DMA_OP2(ap, la, aoffb[0], aoffb[1]);                                                 \
+    else if constexpr (NPA == 2) DMDX_DMA_OP2(ap, la, aoffb[0], aoffb[NPA - 1]);                   \
+    else DMDX_DMA_OP1(ap, la, aoffb[0]);                                                           \
   } while (0)
 #define DMDX_DMA_B(bp, lb) DMDX_DMA_OP4(bp, lb, boffb[0], boffb[1], boffb[2], boffb[3])
 #define DMDX_DMA_NEXT(ap, bp, la, lb) \
@@ -391,7 +397,7 @@ __device__ __forceinline__ void tn_unit(const TnParams& p, const int split, cons
     const float* as_ = lds + (st) * STG + frag_a + foff[t];                          \
     const float* bs_ = lds + (st) * STG + OPA + frag_b + foff[t];                    \
     FA[0] = *reinterpret_cast<const f32x4*>(as_);                                    \
-    FA[1] = *reinterpret_cast<const f32x4*>(as_ + 32 * BK);                          \
+    if constexpr (MI >= 2) FA[MI >= 2 ? 1 : 0] = *reinterpret_cast<const f32x4*>(as_ + 32 * BK); \
     if constexpr (MI == 3) FA[MI - 1] = *reinterpret_cast<const f32x4*>(as_ + 64 * BK); \
     FB[0] = *reinterpret_cast<const f32x4*>(bs_);                                    \
     if constexpr (NI == 2) FB[NI - 1] = *reinterpret_cast<const f32x4*>(bs_ + 32 * BK); \
@@ -466,7 +472,7 @@ __device__ __forceinline__ void tn_unit(const TnParams& p, const int split, cons
           if constexpr (NI == 2) { DMDX_FOLD(0, NI - 1); }
           else if constexpr (MI == 3) { DMDX_FOLD(MI - 1, 0); }
           break;
-        case 2: DMDX_FOLD(1, 0); break;
+        case 2: if constexpr (MI >= 2) { DMDX_FOLD(MI >= 2 ? 1 : 0, 0); } break;
         default: if constexpr (NI == 2) { DMDX_FOLD(1, NI - 1); } break;
       }
     }
@@ -495,6 +501,7 @@ __device__ __forceinline__ void tn_unit(const TnParams& p, const int split, cons
 #undef DMDX_DMA_B
 #undef DMDX_DMA_OP4
 #undef DMDX_DMA_OP2
+#undef DMDX_DMA_OP1
 #undef DMDX_DMA_OP3
 #undef DMDX_FOLD
 #undef DMDX_COMMIT_ALL
@@ -638,9 +645,9 @@ Plan make_plan(int64_t K, int64_t nrow, int64_t ncol, int syrk, int share = 1) {
   pl.syrk = syrk;
   if (!syrk) {  // fewest padded rows; ties go to the taller tile (fewer re-reads of the B panels)
     int64_t best = (nrow + BT - 1) / BT * BT;
-    for (int tm : {96, 64}) {
+    for (int tm : {96, 64, 32}) {
       const int64_t padded = (nrow + tm - 1) / tm * tm;
-      if (padded < best) { best = padded; pl.tm = tm; }
+      if (padded < best && (tm > 32 || nrow <= 32)) { best = padded; pl.tm = tm; }   // 32-row tiles: single tile row only
     }
   }
   pl.ntr = (int)((nrow + pl.tm - 1) / pl.tm);
@@ -714,12 +721,16 @@ int run_tn(const float* A, int64_t lda, const float* B, int64_t ldb, int64_t K, 
     hipLaunchKernelGGL((gemm_tn_partial_kernel<true, 0, 2>), grid, dim3(NTH), 0, stream, p);
   else if (aligned && pl.tm == 96)
     hipLaunchKernelGGL((gemm_tn_partial_kernel<true, 0, 3>), grid, dim3(NTH), 0, stream, p);
+  else if (aligned && pl.tm == 32)
+    hipLaunchKernelGGL((gemm_tn_partial_kernel<true, 0, 1>), grid, dim3(NTH), 0, stream, p);
   else if (aligned)
     hipLaunchKernelGGL(gemm_tn_partial_kernel<true>, grid, dim3(NTH), 0, stream, p);
   else if (pl.tm == 64)
     hipLaunchKernelGGL((gemm_tn_partial_kernel<false, 0, 2>), grid, dim3(NTH), 0, stream, p);
   else if (pl.tm == 96)
     hipLaunchKernelGGL((gemm_tn_partial_kernel<false, 0, 3>), grid, dim3(NTH), 0, stream, p);
+  else if (pl.tm == 32)
+    hipLaunchKernelGGL((gemm_tn_partial_kernel<false, 0, 1>), grid, dim3(NTH), 0, stream, p);
   else
     hipLaunchKernelGGL(gemm_tn_partial_kernel<false>, grid, dim3(NTH), 0, stream, p);
   DMDX_LAUNCH_CHECK();
@@ -794,6 +805,9 @@ int run_batch(const float* const* A, const int64_t* lda, const float* const* B, 
     } else if (pl.tm == 96) {
       if (aligned) hipLaunchKernelGGL((syrk_batch_kernel<true, 3>), grid, dim3(NTH), 0, stream, p, bt);
       else hipLaunchKernelGGL((syrk_batch_kernel<false, 3>), grid, dim3(NTH), 0, stream, p, bt);
+    } else if (pl.tm == 32) {
+      if (aligned) hipLaunchKernelGGL((syrk_batch_kernel<true, 1>), grid, dim3(NTH), 0, stream, p, bt);
+      else hipLaunchKernelGGL((syrk_batch_kernel<false, 1>), grid, dim3(NTH), 0, stream, p, bt);
     } else {
       if (aligned) hipLaunchKernelGGL((syrk_batch_kernel<true, 0>), grid, dim3(NTH), 0, stream, p, bt);
       else hipLaunchKernelGGL((syrk_batch_kernel<false, 0>), grid, dim3(NTH), 0, stream, p, bt);

@@ -358,6 +358,10 @@ def _device_pipeline(ds: Dataset, parsed_config: dict, comm=None, kern=None, dev
     wide = rows_global < len(take) - d + 1
     shard = f" (rank {comm.rank} of {comm.world_size}: latitude rows {band[0]}:{band[1]})" if band else ""
     stream_bytes = int(os.environ.get("DMDX_STREAM_BYTES", "0"))      # > 0 forces the streaming path (tests)
+    # what can be streamed from the file in passes when X does not fit: the standard path on centred
+    # rows (its exact mean deflation would need further passes), the randomized path as it is
+    can_stream = (not wide and not parsed_config["save_data_matrix"]
+                  and (parsed_config["svd_type"] == "randomized" or center))
     if device.type == "cuda" and not stream_bytes:
         # X should be resident: find out before the allocator does
         rows = len(names) * nlev * ((band[1] - band[0]) if band else nlat) * nlon
@@ -368,7 +372,7 @@ def _device_pipeline(ds: Dataset, parsed_config: dict, comm=None, kern=None, dev
             flags = comm.allgather(torch.tensor([1 if fits else 0], dtype=torch.int64, device=device))
             fits = all(int(f.item()) for f in flags)
         if not fits:
-            if parsed_config["svd_type"] == "standard" and center and not parsed_config["save_data_matrix"] and not wide:
+            if can_stream:
                 stream_bytes = max(1 << 30, min(free // 3, 32 << 30))
             else:
                 ranks = -(-4 * len(names) * nlev * nlat * nlon * len(take) // max(free - (12 << 30), 1 << 30))
@@ -376,15 +380,16 @@ def _device_pipeline(ds: Dataset, parsed_config: dict, comm=None, kern=None, dev
                     f"the snapshot matrix of this rank ({rows} x {len(take)} fp32 = {4 * rows * len(take) / 1e9:.1f} GB) "
                     f"does not fit the {free / 1e9:.1f} GB of free HBM; shard the space points over more GPUs: "
                     f"python -m torch.distributed.run --nproc-per-node N -m dmd_era5_amd.era5_svd with N >= "
-                    f"{max(ranks, comm.world_size + 1)} (svd_type = standard with mean_center and without "
-                    "save_data_matrix streams such a slice from the file in two passes instead)")
+                    f"{max(ranks, comm.world_size + 1)} (without save_data_matrix -- and, for svd_type = standard, "
+                    "with mean_center -- such a slice is streamed from the file in passes instead)")
 
     blocks = []
     if stream_bytes:
         # X does not fit: the Gram is accumulated and the projection made while latitude sub-bands of
         # the variables pass through the HBM, twice (svd.svd_snapshots_streaming)
-        if parsed_config["svd_type"] != "standard" or not center or parsed_config["save_data_matrix"] or wide:
-            raise ValueError("the streaming path covers svd_type = standard with mean_center and without save_data_matrix")
+        if not can_stream:
+            raise ValueError("the streaming path needs save_data_matrix = False, a tall problem and, for "
+                             "svd_type = standard, mean_center = True")
         i0, i1 = band if band else (0, nlat)
         h = max(1, stream_bytes // max(1, 4 * len(take) * nlev * nlon))       # latitude rows per piece
         sub = [(j, min(i1, j + h)) for j in range(i0, i1, h)]
@@ -395,7 +400,8 @@ def _device_pipeline(ds: Dataset, parsed_config: dict, comm=None, kern=None, dev
                 for j0, j1 in sub:
                     st = {"mean": [], "std": []}
                     vb, _, nbytes = _upload_variable(ds[name], level_idx, take, device, kern, center, scale, st, (j0, j1))
-                    means[(vi, j0)] = torch.cat(st["mean"])
+                    if center:
+                        means[(vi, j0)] = torch.cat(st["mean"])
                     if scale:
                         stds[(vi, j0)] = torch.cat(st["std"])
                     moved[0] += nbytes
@@ -403,9 +409,13 @@ def _device_pipeline(ds: Dataset, parsed_config: dict, comm=None, kern=None, dev
 
         t0 = _time.perf_counter()
         log_and_print(logger, f"Snapshot matrix larger than the HBM: streaming it in {len(names) * len(sub)} pieces of "
-                              f"<= {h} latitude rows, two passes{shard}")
-        log_and_print(logger, "Performing standard SVD...")
-        Ub, s_, Vh_, sinfo = dsvd.svd_snapshots_streaming(pieces, k, rows_global, delay=d, comm=comm, kern=kern)
+                              f"<= {h} latitude rows{shard}")
+        log_and_print(logger, f"Performing {parsed_config['svd_type']} SVD...")
+        if parsed_config["svd_type"] == "standard":
+            Ub, s_, Vh_, sinfo = dsvd.svd_snapshots_streaming(pieces, k, rows_global, delay=d, comm=comm, kern=kern)
+        else:
+            Ub, s_, Vh_, sinfo = dsvd.svd_randomized_streaming(pieces, k, rows_global, len(take), delay=d, comm=comm,
+                                                               kern=kern, **_engine_opts(parsed_config))
         if sinfo.get("warning"):
             log_and_print(logger, "WARNING: " + sinfo["warning"])
         kk = int(s_.numel())
@@ -416,18 +426,21 @@ def _device_pipeline(ds: Dataset, parsed_config: dict, comm=None, kern=None, dev
         for vi in range(len(names)):
             for j0, j1 in sub:      # a piece's rows: (level, its latitude rows, longitude), embedded as k_delay * m_piece + s
                 Ul[:, :, vi, :, j0 - i0:j1 - i0, :] = dsvd._assemble_rows(Ub[idx], d).reshape(kk, d, nlev, j1 - j0, nlon)
-                mean_l[vi, :, j0 - i0:j1 - i0, :] = means[(vi, j0)].reshape(nlev, j1 - j0, nlon)
+                if center:
+                    mean_l[vi, :, j0 - i0:j1 - i0, :] = means[(vi, j0)].reshape(nlev, j1 - j0, nlon)
                 if scale:
                     std_l[vi, :, j0 - i0:j1 - i0, :] = stds[(vi, j0)].reshape(nlev, j1 - j0, nlon)
                 Ub[idx] = None
                 idx += 1
         res = dsvd.SvdResult(Ut=Ul.reshape(kk, -1), s=s_, Vh=Vh_, info=sinfo)
         stats = {"mean": [mean_l.reshape(-1)], "std": [std_l.reshape(-1)] if scale else []}
-        total = moved[0] // 2
+        npass = int(sinfo.get("passes_over_X", 2))
+        total = moved[0] // npass
         sync()
         dt = _time.perf_counter() - t0
-        log_and_print(logger, "Standard SVD complete.")
-        log_and_print(logger, f"Ingest + SVD (streamed twice): {dt:.2f} s ({2 * total / 1e9 / max(dt, 1e-9):.1f} GB/s of file data)")
+        log_and_print(logger, f"{parsed_config['svd_type'].capitalize()} SVD complete.")
+        log_and_print(logger, f"Ingest + SVD ({npass} passes over the file): {dt:.2f} s "
+                              f"({npass * total / 1e9 / max(dt, 1e-9):.1f} GB/s of file data)")
         t0 = _time.perf_counter()
     else:
         t0 = _time.perf_counter()

@@ -43,6 +43,7 @@ __all__ = [
     "top_eigh",
     "svd_snapshots",
     "svd_snapshots_streaming",
+    "svd_randomized_streaming",
     "svd_randomized",
 ]
 
@@ -744,6 +745,74 @@ def svd_snapshots_streaming(pieces, n_components: int, rows_global: int, delay: 
         _, Vh = _sign_flip([U for piece in Ub for U in piece], Vh, comm, kern)
     info.update(l=l, k=k, nd=nd)
     return Ub, s, Vh, info
+
+
+def svd_randomized_streaming(pieces, n_components: int, rows_global: int, n_time: int, delay: int = 1,
+                             n_oversamples: int = 10, n_iter="auto", omega=None, random_state=None,
+                             flip_sign: bool = True, comm: Comm | None = None, kern=None) -> tuple:
+    """Randomized SVD for an X that does not fit the HBM (``pieces()`` as in
+    :func:`svd_snapshots_streaming`): ONE pass over X per power iteration -- while a piece is
+    resident, Y_p = E_p Q and Z += E_p^T Y_p are both formed and Y_p is dropped -- plus one pass
+    for the final Y = E Q (kept: m x l) and one for B = Q^T E; n_iter + 2 passes instead of the
+    2 n_iter + 2 of the resident path.  The price: Y is not orthonormalised between the two half
+    steps (only Q = orth(Z) once per iteration), i.e. sklearn's iterate with one normalisation per
+    full step -- same subspaces in exact arithmetic, a conditioning of (s_1 / s_l)^2 per step
+    instead of s_1 / s_l, which fp32 storage of Y carries for the spectra this path is for.
+    Returns (Ublocks, s, Vh, info) like the streaming standard path."""
+    kern = _kern(kern)
+    comm = comm or Comm()
+    nd = n_time - delay + 1
+    k = min(n_components, nd, rows_global)
+    l = min(n_components + n_oversamples, nd, rows_global)
+    n_it = resolve_n_iter(n_components, rows_global, nd, n_iter)
+    if omega is None:
+        rs = random_state if isinstance(random_state, np.random.RandomState) else np.random.RandomState(random_state)
+        omega = rs.normal(size=(nd, n_components + n_oversamples))[:, :l]
+    omega = torch.as_tensor(np.ascontiguousarray(np.asarray(omega).T, dtype=np.float32)) if not isinstance(omega, torch.Tensor) \
+        else omega.T.contiguous().to(torch.float32)
+    if tuple(omega.shape) != (l, nd):
+        raise ValueError(f"omega must be ({nd}, {l}), got {tuple(omega.shape)[::-1]}")
+    Qt, dev = None, None
+    for _ in range(n_it):
+        Z = None
+        for blocks in pieces():
+            if Qt is None:
+                dev = blocks[0].device
+                Qt = omega.to(dev)
+            Qp = _pitched(kern, Qt)
+            Eb = [embed_view(B, delay) for B in blocks]
+            Yb = [kern.skinny(E, Qp) for E in Eb]
+            Z = kern.gemm_tn_blocks(Eb, Yb, out=Z) if (Z is not None or len(Eb) > 1) else kern.gemm_tn(Eb[0], Yb[0])
+            del Yb
+        comm.allreduce_sum_(Z)
+        if not bool(torch.isfinite(Z).all()):
+            raise np.linalg.LinAlgError("SVD did not converge")
+        Zn = Z / torch.linalg.vector_norm(Z, dim=1, keepdim=True).clamp_min(1e-300)
+        Qt = comm.broadcast_(_orth(Zn.T.contiguous()).T.contiguous().to(torch.float32))
+    Yp, bounds = [], [0]
+    for blocks in pieces():
+        if Qt is None:
+            dev = blocks[0].device
+            Qt = omega.to(dev)
+        Qp = _pitched(kern, Qt)
+        Yp.extend(kern.skinny(embed_view(B, delay), Qp) for B in blocks)
+        bounds.append(len(Yp))
+    Qm = _cholqr(Yp, comm, kern, passes=2)                    # orthonormal basis of range(Y), all pieces
+    Bm = None
+    for pi, blocks in enumerate(pieces()):                     # B = Q^T E, piece by piece
+        Eb = [embed_view(B, delay) for B in blocks]
+        Qb = Qm[bounds[pi]:bounds[pi + 1]]
+        Bm = kern.gemm_tn_blocks(Eb, Qb, out=Bm) if (Bm is not None or len(Eb) > 1) else kern.gemm_tn(Eb[0], Qb[0])
+    comm.allreduce_sum_(Bm)
+    Uhat, s, Vh = torch.linalg.svd(Bm, full_matrices=False)
+    Uhat, s, Vh = Uhat.contiguous(), s.contiguous(), Vh.contiguous()
+    comm.broadcast_(Uhat, s, Vh)
+    Uk = _pitched(kern, Uhat[:, :k].T.contiguous().to(torch.float32))
+    Ub = [[kern.skinny(Q, Uk) for Q in Qm[bounds[pi]:bounds[pi + 1]]] for pi in range(len(bounds) - 1)]
+    s, Vh = s[:k], Vh[:k].contiguous()
+    if flip_sign:
+        _, Vh = _sign_flip([U for piece in Ub for U in piece], Vh, comm, kern)
+    return Ub, s, Vh, {"streaming": True, "l": l, "k": k, "nd": nd, "n_iter": n_it, "passes_over_X": n_it + 2}
 
 
 # ---------------------------------------------------------------------------

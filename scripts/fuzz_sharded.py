@@ -79,7 +79,7 @@ if __name__ == "__main__":
                "_lazy": bool(rs.rand() < 0.7), "_slab": int(rs.choice([1 << 16, 1 << 20, 1 << 28])), "_variables": [names[j] for j in use]}
         # half of the eligible cases go through the two-pass streaming path (pieces of a few latitude rows)
         cfg["_stream"] = 0
-        if cfg["svd_type"] == "standard" and center and rs.rand() < 0.5:
+        if (cfg["svd_type"] == "randomized" or center) and rs.rand() < 0.5:
             cfg["save_data_matrix"] = False
             cfg["_stream"] = int(rs.randint(2, 15)) * 4 * hours * len(sel) * 72
         world = int(rs.choice([1, 2, 3, 5])) if cfg["_stream"] else int(rs.choice([2, 3, 5]))

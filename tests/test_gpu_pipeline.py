@@ -346,19 +346,20 @@ def test_main_on_a_wide_problem(svd_base_config, project_root, svd_type):
     assert np.all(U[np.abs(U).argmax(axis=0), np.arange(3)] > 0)              # u-based sign convention
 
 
-@pytest.mark.parametrize("d,scale", [(1, False), (2, True)])
-def test_main_streams_a_slice_that_does_not_fit(svd_base_config, tmp_path, monkeypatch, d, scale):
-    """svd_type = standard with mean_center: a snapshot matrix larger than the free HBM is streamed
-    from the file in two passes (Gram, projection) instead of being refused.  Forced by a piece
-    budget of 5 latitude rows; the result must equal the resident run on the same slice."""
+@pytest.mark.parametrize("svd_type,d,scale", [("standard", 1, False), ("standard", 2, True), ("randomized", 2, False)])
+def test_main_streams_a_slice_that_does_not_fit(svd_base_config, tmp_path, monkeypatch, svd_type, d, scale):
+    """A snapshot matrix larger than the free HBM is streamed from the file in passes instead of
+    being refused (standard with mean_center: Gram pass + projection pass; randomized: one pass
+    per power iteration + two).  Forced by a piece budget of 5 latitude rows; the result must equal
+    the resident run on the same slice."""
     from dmd_era5_amd import io_netcdf
     from dmd_era5_amd.config_parser import config_parser
     from dmd_era5_amd.create_mock_data import add_download_attributes, create_mock_era5
     from dmd_era5_amd.era5_svd import main
 
     cfg = dict(svd_base_config, start_datetime="2019-01-01T00", end_datetime="2019-01-04T00",
-               variables="temperature,u_component_of_wind", levels="1000,500", svd_type="standard",
-               mean_center=True, scale=scale, delay_embedding=d, n_components=3, save_data_matrix=False)
+               variables="temperature,u_component_of_wind", levels="1000,500", svd_type=svd_type,
+               mean_center=True, scale=scale, delay_embedding=d, n_components=3, save_data_matrix=False, svd_seed=0)
     out = {}
     for tag in ("resident", "streamed"):
         root = tmp_path / tag
@@ -382,9 +383,10 @@ def test_main_streams_a_slice_that_does_not_fit(svd_base_config, tmp_path, monke
         monkeypatch.delenv("DMDX_STREAM_BYTES", raising=False)
     a, b = out["resident"], out["streamed"]
     assert sorted(a.data_vars) == sorted(b.data_vars) and "X" not in b.data_vars
-    assert np.allclose(b["s"].values, a["s"].values, rtol=1e-6)
+    assert np.allclose(b["s"].values, a["s"].values, rtol=1e-6 if svd_type == "standard" else 1e-5)
     assert np.abs(b["U"].values - a["U"].values).max() < 1e-4 * np.abs(a["U"].values).max()
     assert np.abs(b["V"].values - a["V"].values).max() < 1e-5
     if d > 1:
         assert np.array_equal(b["X_mean"].values, a["X_mean"].values)
-        assert np.allclose(b["X_std"].values, a["X_std"].values, rtol=1e-6)
+        if scale:
+            assert np.allclose(b["X_std"].values, a["X_std"].values, rtol=1e-6)

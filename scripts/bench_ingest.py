@@ -13,7 +13,7 @@ from dmd_era5_amd.era5_svd import main
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 end = str((np.datetime64("2019-01-01T00") + np.timedelta64(n - 1, "h")).astype("datetime64[h]"))
 cfg = {"source_path": "synthetic", "variables": "temperature", "levels": "1000",
-       "svd_type": "standard", "delay_embedding": 2, "mean_center": True, "scale": False,
+       "svd_type": sys.argv[2] if len(sys.argv) > 2 else "standard", "svd_seed": 0, "delay_embedding": 2, "mean_center": True, "scale": False,
        "start_datetime": "2019-01-01T00", "end_datetime": end, "delta_time": "1h",
        "n_components": 20, "save_data_matrix": False}
 p = config_parser(cfg, "era5-svd")

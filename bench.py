@@ -81,6 +81,32 @@ def make_snapshot_blocks(m: int, n: int, seed: int, device, shard: int = 0) -> l
     return blocks
 
 
+def make_powerlaw_blocks(m: int, n: int, seed: int, device, shard: int = 0) -> list[torch.Tensor]:
+    """The gap-free counterpart of :func:`make_snapshot_blocks` (ERA5 anomalies have power-law
+    spectra, not a gap behind the wanted rank): X = X0 W with X0 (m x n) Gaussian noise and
+    W = B diag(sigma) H^T / sqrt(m_total-ish), B and H random orthogonal (n x n), sigma_i = 100 / i
+    over ALL n columns.  X0^T X0 / m = I + O(sqrt(n/m)), so the singular values of X are
+    sigma_i sqrt(m) within the Marchenko-Pastur edge factors 1 +- sqrt(n/m) and every consecutive
+    ratio is (i+1)/i: no gap anywhere.  Row blocks as (n, mb) fp32 tensors; the time factor W is
+    the same for every shard (one global matrix, as in make_snapshot_blocks)."""
+    from dmd_era5_amd.svd import split_rows
+
+    g = torch.Generator(device=device).manual_seed(seed)
+    Bq, _ = torch.linalg.qr(torch.randn((n, n), generator=g, device=device, dtype=torch.float32))
+    Hq, _ = torch.linalg.qr(torch.randn((n, n), generator=g, device=device, dtype=torch.float32))
+    sig = 100.0 / torch.arange(1, n + 1, device=device, dtype=torch.float32)
+    Wt = (Hq * sig) @ Bq.T                      # (n, n) = W^T:  X_b^T = W^T X0_b^T
+    del Bq, Hq
+    if shard:
+        g = torch.Generator(device=device).manual_seed(seed + 1000003 * shard)
+    blocks = []
+    for r0, r1 in split_rows(m):
+        X0t = torch.randn((n, r1 - r0), generator=g, device=device, dtype=torch.float32)
+        blocks.append(Wt @ X0t)
+        del X0t
+    return blocks
+
+
 def calibrate(device) -> dict:
     """What this GPU sustains, next to the nominal peaks the roofline is priced against
     (SURVEY.md 8d): a register-only fp32 MFMA loop (dmdx_calib_mfma_f32, 2 waves per SIMD) and a

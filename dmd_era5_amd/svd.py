@@ -164,16 +164,27 @@ def embed_view(Xt: torch.Tensor, d: int) -> torch.Tensor:
 # ---------------------------------------------------------------------------
 # small dense pieces (fp64, torch)
 # ---------------------------------------------------------------------------
-def _orth(Y: torch.Tensor) -> torch.Tensor:
+def _orth(Y: torch.Tensor, rounds: int = 2) -> torch.Tensor:
     """Orthonormal basis of the columns of a tall fp64 block.  CholeskyQR2 (two rounds of
     Gram -> Cholesky -> triangular solve: three small GEMM-type calls, ~1 ms at 8760 x 210)
-    instead of Householder QR (rocSOLVER geqrf+orgqr: ~9 ms); falls back to Householder when
-    the block is too ill-conditioned for the Gram route."""
+    instead of Householder QR (rocSOLVER geqrf+orgqr: ~9 ms).  A block too ill-conditioned for
+    the plain Gram route (cond > ~1e8: G times a random block of a low-rank + noise matrix spans
+    lambda_1 / lambda_noise) first gets a *shifted* round (Fukaya et al. 2020: factor
+    Y^T Y + s I, s ~ 1e-11 |Y|^2, which caps the conditioning of what the plain rounds then see),
+    and only if that fails too Householder QR.  ``rounds=1``: conditioning control between the
+    factors of a polynomial filter (orthogonal to ~cond^2 eps), not an orthonormal basis."""
     Q = Y
-    for _ in range(2):
+    for it in range(rounds):
         G = Q.T @ Q
         L, err = torch.linalg.cholesky_ex(G)
         if int(err) != 0 or not torch.isfinite(L).all():
+            if it == 0:
+                tr = torch.diagonal(G).sum()
+                for rel in (1e-11, 1e-8):
+                    L, err = torch.linalg.cholesky_ex(G + (rel * tr) * torch.eye(G.shape[0], dtype=G.dtype, device=G.device))
+                    if int(err) == 0 and bool(torch.isfinite(L).all()):
+                        Qs = torch.linalg.solve_triangular(L, Q.T, upper=False).T
+                        return _orth(Qs, rounds=2) if rel == 1e-11 else _orth(_orth(Qs, rounds=1), rounds=2)
             Qh, _ = torch.linalg.qr(Y, mode="reduced")
             return Qh
         Q = torch.linalg.solve_triangular(L, Q.T, upper=False).T
@@ -223,31 +234,61 @@ def _graded_eigh(s0: torch.Tensor, Mm: torch.Tensor, kern=None):
     return mu, Z
 
 
+# Cost model of the eigen stage on the MI355X (scripts/probe_powerlaw.py, fp64): a product G @ Q
+# takes ~1.0 ms at n = 8760 for any block up to 312 columns (rocBLAS, tall-skinny), CholeskyQR2
+# ~0.9 ms at 77 columns / 1.2 at 124 / 2.5 at 312; the library's full solver (syevd) 816 / 142 /
+# 50 ms at n = 8760 / 4000 / 2000.
+def _full_eigh_ms(n: int) -> float:
+    return 816.0 * (n / 8760.0) ** 2
+
+
+def _filter_step_ms(n: int, b: int) -> float:
+    return max(0.25, 1.0 * (n / 8760.0) ** 2) + 0.6 + 0.006 * b
+
+
 def top_eigh(G: torch.Tensor, l: int, method: str = "auto", tol: float = 1e-9,
              max_outer: int = 40, info: dict | None = None, kern=None):
     """Largest ``l`` eigenpairs of the symmetric PSD fp64 matrix ``G`` (n x n),
     eigenvalues descending.
 
-    ``full``: torch.linalg.eigh.  ``krylov``: block power steps, then restarted block Krylov with
-    Rayleigh-Ritz (only products G @ block, thin QRs and a (3b x 3b) eigh), run
-    until every wanted pair has residual <= tol * lambda_1 (default 1e-9: the level of G's own
-    rounding error -- its entries are sums of fp32 products --, i.e. the pairs returned are exact
-    for a matrix as close to X^T X as G itself is), falling back to the
-    full solver if that does not happen.  ``auto`` picks by size.
+    ``full``: torch.linalg.eigh.  ``cheb`` (alias ``krylov``, the name of the restarted block
+    Krylov solver this replaced): block power steps, then a Chebyshev-filtered subspace iteration
+    -- only products G @ block, CholeskyQR2 and (b x b) Rayleigh-Ritz steps --, run until every
+    wanted pair has residual <= tol * lambda_1 (default 1e-9: the level of G's own rounding error
+    -- its entries are sums of fp32 products --, i.e. the pairs returned are exact for a matrix as
+    close to X^T X as G itself is).  ``auto`` picks by size.
+
+    The filter.  With the block's smallest Ritz value c as the cut, the degree-d Chebyshev
+    polynomial of [0, c] damps everything G has below the block and grows like rho^d above it,
+    rho = x + sqrt(x^2 - 1), x = 2 lambda / c - 1: a gap-free spectrum lambda_i ~ i^-2 (ERA5
+    anomalies are power-law, not low-rank + noise) with l = 62, b = 124 gains a factor 14 per
+    product on the slowest wanted pair where a power step gains 4.  The spectrum of a snapshot Gram
+    spans many decades inside the block (lambda_1 / lambda_l ~ 4000), so the three-term recurrence
+    cannot be run on the block as it stands -- after d steps the columns have collapsed onto the
+    leading eigenvectors by (lambda_1 / lambda_l)^d --; the polynomial is applied instead as the
+    product of its linear factors, Q <- orth((G - r_i I) Q) over the d Chebyshev roots r_i of
+    [0, c]: the same subspace, each step a shifted power step whose block stays well inside the
+    range of CholeskyQR2.  The degree of every pass is forecast from the residual and the rho of
+    the slowest wanted pair, a Rayleigh-Ritz step follows each pass.  When the forecast says the
+    remaining passes cost more than the library's full solver (flat spectra -- pure noise has no
+    gap for any polynomial to use -- at sizes where syevd is cheap) the full solver is taken at
+    once; the rule is a function of n and the residuals only, so every rank and every run takes
+    the same branch.
     """
     n = G.shape[0]
     l = min(l, n)
     # auto (measured on the MI355X, l = 62: scripts/probe_eig_threshold.py): the block power steps
     # cost 3-4 ms whatever n is and finish every steep spectrum; the library solver costs 9 / 17 /
-    # 23 / 36 ms at n = 384 / 768 / 1024 / 1536 and a Krylov sweep sequence ~19 ms whatever n is.
-    # So: power steps first unless the block would be most of the matrix, then the full solver up
-    # to n = 1024, Krylov sweeps above.
+    # 23 / 36 ms at n = 384 / 768 / 1024 / 1536.  So: power steps first unless the block would be
+    # most of the matrix, then the full solver up to n = 1024, the filtered iteration above.
     full_after_power = False
+    if method == "krylov":
+        method = "cheb"
     if method == "auto":
         if n <= 256 or 4 * l >= n:
             method = "full"
         else:
-            method, full_after_power = "krylov", n <= 1024
+            method, full_after_power = "cheb", n <= 1024
     if method == "full":
         lam, V = torch.linalg.eigh(G)
         lam = torch.flip(lam[-l:], dims=(0,))
@@ -255,80 +296,115 @@ def top_eigh(G: torch.Tensor, l: int, method: str = "auto", tol: float = 1e-9,
         if info is not None:
             info["eig_method"] = "full"
         return lam, V.contiguous()
+    if method != "cheb":
+        raise ValueError(f"top_eigh: unknown method {method!r}")
 
     b = min(n // 3, l + max(8, l // 4))
     gen = torch.Generator(device=G.device).manual_seed(1234)  # (a host draw + upload costs 7 ms)
     Q = torch.randn((n, b), dtype=torch.float64, generator=gen, device=G.device)
     Q = _orth(G @ Q)
+    products = 1
 
-    def ritz(S, GS, want):
-        """Rayleigh-Ritz of G in span(S) (S orthonormal, GS = G S): Ritz values (descending),
-        Ritz vectors of the leading `want`, and the residual of the leading l relative to theta_1."""
+    def ritz(S, GS):
+        """Rayleigh-Ritz of G in span(S) (S orthonormal, GS = G S): Ritz values (descending), Ritz
+        vectors Qn, G Qn, and the residual norms of all of them relative to theta_1."""
         T = S.T @ GS
         T = 0.5 * (T + T.T)
         th, Z = _eigh_desc(T, kern)
-        th, Z = th[:want], Z[:, :want]
         Qn = S @ Z
-        R = GS @ Z[:, :l] - Qn[:, :l] * th[:l]
-        res = float(torch.linalg.vector_norm(R, dim=0).max() / th[0].abs().clamp_min(1e-300))
-        return th, Qn, res
+        GQn = GS @ Z
+        res = torch.linalg.vector_norm(GQn - Qn * th, dim=0) / th[0].abs().clamp_min(1e-300)
+        return th, Qn, GQn, res
 
     def done(th, Qn, res, how, it):
         if info is not None:
             info["eig_method"] = how
             info["eig_outer_iters"] = it
             info["eig_residual"] = res
+            info["eig_products"] = products
+            info["eig_block"] = int(Qn.shape[1])
         return th[:l].contiguous(), Qn[:, :l].contiguous()
 
-    # Fast path: block power steps with a (b x b) Rayleigh-Ritz (K7) after the 2nd and the 3rd
-    # step.  With a steep spectrum behind the block (lambda_{b+1} << lambda_l: every low-rank +
-    # noise matrix, cfg2, where the fp32 rounding of G leaves a floor of ~1e-9 lambda_1 and each
-    # step gains ~3 digits) this reaches the tolerance for a fraction of the cost of a Krylov
-    # sweep ((3b x 3b) eigensolve, (n x 3b) orthonormalisation); otherwise its Ritz vectors are
-    # the start of the Krylov sweeps.
+    # Fast path: block power steps with a (b x b) Rayleigh-Ritz (K7) after the 2nd -- and, if the
+    # Ritz values say one more round (two products, each gaining theta_j / theta_b on pair j) will
+    # do, after the 4th.  With a steep spectrum behind the block (lambda_{b+1} << lambda_l: every
+    # low-rank + noise matrix, cfg2, where the fp32 rounding of G leaves a floor of ~1e-9 lambda_1
+    # and each step gains ~3 digits) this reaches the tolerance after 3 products; otherwise its
+    # Ritz vectors are the start of the filtered iteration.
     for it in range(2):
         Q = _orth(G @ Q)
         Y = G @ Q
-        th, Qn, res = ritz(Q, Y, b)
+        products += 2
+        th, Q, GQ, resv = ritz(Q, Y)
+        res = float(resv[:l].max())
         if res <= tol:
-            return done(th, Qn, res, "power", it + 1)
-        Q = Qn
+            return done(th, Q, res, "power", it + 1)
+        if it == 0:
+            gain = (th[:l] / th[b - 1].clamp_min(1e-300)) ** 2
+            if not bool((resv[:l] <= tol * gain).all()):
+                break
     if full_after_power:
         return top_eigh(G, l, method="full", info=info, kern=kern)
 
-    def orth_against(Y, P):
-        """Orthonormal basis of the part of span(Y) outside span(P) (P orthonormal): block
-        Gram-Schmidt, projected twice, then CholeskyQR2 inside the block."""
+    # Widen the block for the filter (its growth rate per product is set by lambda_l / lambda_{b+1}):
+    # 2 l columns, the new ones G-multiplied noise orthogonalised against the Ritz vectors; G Q of
+    # the old ones is known from the Rayleigh-Ritz step, so this costs two products.
+    b2 = min(n // 3, max(b, 2 * l))
+    if b2 > b:
+        W = G @ torch.randn((n, b2 - b), dtype=torch.float64, generator=gen, device=G.device)
         for _ in range(2):
-            Y = Y - P @ (P.T @ Y)
-        return _orth(Y)
-
-    # A sweep costs about as much as 1/45 of the full solver at n = 8760, b = 62 and relatively more
-    # for smaller n / wider blocks (measured: 18 / 9 / 5.5 ms per sweep against 816 / 142 / 50 ms of
-    # syevd at n = 8760 / 4000 / 2000): when the residual history forecasts more sweeps than twice
-    # that break-even (flat spectra -- pure noise has no gap for a Krylov method to use), stop
-    # early and solve the whole matrix.  The rule is a function of the residuals only, so every
-    # rank and every run takes the same branch.
-    break_even = min(float(max_outer), max(6.0, n / 200.0 * 62.0 / b))
-    prev = res
-    for it in range(max_outer):
-        Y1 = orth_against(G @ Q, Q)
-        P = torch.cat([Q, Y1], dim=1)
-        Y2 = orth_against(G @ Y1, P)
-        S = torch.cat([P, Y2], dim=1)
-        th, Q, res = ritz(S, G @ S, b)
+            W = W - Q @ (Q.T @ W)
+        W = _orth(W)
+        th, Q, GQ, resv = ritz(torch.cat([Q, W], dim=1), torch.cat([GQ, G @ W], dim=1))
+        products += 2
+        b = b2
+        res = float(resv[:l].max())
         if res <= tol:
-            return done(th, Q, res, "krylov", it + 1)
-        if it >= 2:
-            rate = res / prev if prev > 0 else 1.0
-            need = math.inf if not (0.0 < rate < 1.0) else math.log(tol / res) / math.log(rate)
-            if it + 1 + need > 2.0 * break_even:
-                if info is not None:
-                    info["eig_krylov_forecast_sweeps"] = float(min(need, 1e9))
-                break
-        prev = res
+            return done(th, Q, res, "power", 2)
+
+    max_deg = 24
+    full_ms = _full_eigh_ms(n)
+    step_ms = _filter_step_ms(n, b)
+    spent = 0
+    degrees: list[int] = []
     if info is not None:
-        info["eig_krylov_failed_residual"] = res
+        info["eig_degrees"] = degrees
+    for it in range(max_outer):
+        host = torch.cat([th, resv]).tolist()          # one transfer: Ritz values + residuals
+        thl, rl = host[:b], host[b:]
+        cut = max(thl[b - 1], 0.0)
+        # the slowest wanted pair: the unconverged one closest to the cut
+        j = max(i for i in range(l) if rl[i] > tol)
+        x = 2.0 * thl[j] / cut - 1.0 if cut > 0.0 else math.inf
+        rho = x + math.sqrt(max(x * x - 1.0, 0.0)) if math.isfinite(x) else math.inf
+        need = math.log(3.0 * rl[j] / tol) / math.log(rho) if rho > 1.0 + 1e-12 else math.inf
+        if not math.isfinite(need) or need * step_ms > full_ms or spent * step_ms > 3.0 * full_ms:
+            if info is not None:
+                info["eig_cheb_forecast_steps"] = float(min(need, 1e9))
+            break
+        # (the first forecast rests on the Ritz values of a freshly widened block: capped lower)
+        deg = int(min(max_deg if it else 10, max(2, math.ceil(1.25 * need) + 1)))
+        degrees.append(deg)
+        roots = [0.5 * cut * (1.0 + math.cos(math.pi * (2 * i + 1) / (2 * deg))) for i in range(deg)]
+        order = []
+        lo, hi = 0, deg - 1
+        while lo <= hi:                                  # large and small roots alternate
+            order += [roots[lo]] if lo == hi else [roots[lo], roots[hi]]
+            lo, hi = lo + 1, hi - 1
+        for i, r_i in enumerate(order):
+            # one CholeskyQR round between the factors (conditioning control), two before the
+            # Rayleigh-Ritz step (an orthonormal basis)
+            Q = _orth(torch.addmm(Q, G, Q, beta=-r_i), rounds=2 if i == deg - 1 else 1)
+        Y = G @ Q
+        products += deg + 1
+        spent += deg
+        th, Q, GQ, resv = ritz(Q, Y)
+        res = float(resv[:l].max())
+        if res <= tol:
+            return done(th, Q, res, "cheb", it + 1)
+    if info is not None:
+        info["eig_cheb_failed_residual"] = res
+        info["eig_products"] = products
     return top_eigh(G, l, method="full", info=info, kern=kern)
 
 

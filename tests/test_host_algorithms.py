@@ -34,27 +34,68 @@ def test_snapshots_matches_golden():
         assert col_cosines(r.Vh.numpy().T, g["V64"].T).min() > 1 - 1e-5
 
 
-def test_top_eigh_krylov_equals_full():
+def _psd_with_spectrum(n, lam, seed):
+    rs = np.random.RandomState(seed)
+    Qm, _ = np.linalg.qr(rs.standard_normal((n, n)))
+    G = (Qm * lam) @ Qm.T
+    return torch.from_numpy(0.5 * (G + G.T))
+
+
+@pytest.mark.parametrize("l,power", [(20, 2.0), (62, 2.0), (40, 1.0)])
+def test_top_eigh_cheb_equals_full_on_gap_free_spectra(l, power):
+    """lambda_i ~ i^-2 (singular values ~ 1/i: what ERA5 anomalies look like) and the slower
+    i^-1: no gap behind any block, so the power steps cannot finish and the Chebyshev-filtered
+    iteration must -- with a handful of products, not by falling back to the full solver."""
+    n = 1500
+    G = _psd_with_spectrum(n, 1.0 / np.arange(1, n + 1) ** power, 0)
+    info = {}
+    lam_k, V_k = dsvd.top_eigh(G, l, method="cheb", info=info, kern=K)
+    lam_f, V_f = dsvd.top_eigh(G, l, method="full")
+    assert info["eig_method"] == "cheb" and info["eig_residual"] <= 1e-9
+    assert info["eig_products"] <= (16 if power == 2.0 else 30) and info["eig_block"] == 2 * l
+    assert torch.allclose(lam_k, lam_f, rtol=1e-10)
+    # vectors: residual 1e-9 lambda_1 over a gap of ~2 lambda_l / l
+    assert (V_k * V_f).sum(dim=0).abs().min() > 1 - 1e-6
+    assert float((V_k.T @ V_k - torch.eye(l, dtype=torch.float64)).abs().max()) < 1e-12
+
+
+def test_top_eigh_krylov_is_an_alias_of_cheb():
     rs = np.random.RandomState(0)
-    A = rs.standard_normal((3000, 400)) * (0.97 ** np.arange(400))
+    A = rs.standard_normal((3000, 1200)) * (0.99 ** np.arange(1200))
     G = torch.from_numpy(A.T @ A)
     info = {}
     lam_k, V_k = dsvd.top_eigh(G, 20, method="krylov", info=info, kern=K)
     lam_f, V_f = dsvd.top_eigh(G, 20, method="full")
-    assert info["eig_method"] == "krylov"
+    assert info["eig_method"] == "cheb"
     assert torch.allclose(lam_k, lam_f, rtol=1e-10)
     assert (V_k * V_f).sum(dim=0).abs().min() > 1 - 1e-8
+    with pytest.raises(ValueError):
+        dsvd.top_eigh(G, 20, method="lanczos")
+
+
+def test_orth_survives_blocks_beyond_choleskyqr():
+    """G times a random block of a low-rank + noise matrix spans lambda_1 / lambda_noise ~ 1e12:
+    the plain Gram route fails there, the shifted round must take over (not Householder QR)."""
+    rs = np.random.RandomState(3)
+    n, b = 600, 40
+    Qm, _ = np.linalg.qr(rs.standard_normal((n, b)))
+    Y = torch.from_numpy(Qm * np.logspace(0, -12, b)) @ torch.from_numpy(rs.standard_normal((b, b)))
+    Q = dsvd._orth(Y)
+    assert float((Q.T @ Q - torch.eye(b, dtype=torch.float64)).abs().max()) < 1e-10
+    # same span as far as fp64 resolves it: the leading directions of Y are inside span(Q)
+    lead = torch.from_numpy(Qm[:, :8])
+    assert float((lead - Q @ (Q.T @ lead)).abs().max()) < 1e-6
 
 
 def test_top_eigh_power_fast_path_on_lowrank_plus_noise():
     """A steep drop behind the block (cfg2's spectrum shape) is finished by the (b x b) power /
-    Rayleigh-Ritz steps; a slowly decaying one (the test above) goes on to the Krylov sweeps."""
+    Rayleigh-Ritz steps; a slowly decaying one (the tests above) goes on to the filtered iteration."""
     rs = np.random.RandomState(1)
     A = rs.standard_normal((4000, 24)) * (100 * 0.9 ** np.arange(24))   # rank 24 < block width 28
     X = A @ rs.standard_normal((24, 500)) + 1e-3 * rs.standard_normal((4000, 500))
     G = torch.from_numpy(X.T @ X)
     info = {}
-    lam_p, V_p = dsvd.top_eigh(G, 20, method="krylov", info=info, kern=K)
+    lam_p, V_p = dsvd.top_eigh(G, 20, method="cheb", info=info, kern=K)
     lam_f, V_f = dsvd.top_eigh(G, 20, method="full")
     assert info["eig_method"] == "power" and info["eig_residual"] <= 1e-11
     assert torch.allclose(lam_p, lam_f, rtol=1e-10)
@@ -62,15 +103,15 @@ def test_top_eigh_power_fast_path_on_lowrank_plus_noise():
 
 
 def test_top_eigh_flat_spectrum_goes_to_the_full_solver_early():
-    """Pure noise has no spectral gap: the residual history forecasts far more Krylov sweeps than
-    the full solver costs, so the sweeps stop after a few and the answer comes from eigh."""
+    """Pure noise has no spectral gap: the Ritz values forecast far more filter steps than the
+    full solver costs at this size, so the answer comes from eigh at once."""
     rs = np.random.RandomState(2)
     A = rs.standard_normal((6000, 1800))
     G = torch.from_numpy(A.T @ A)
     info = {}
-    lam_a, V_a = dsvd.top_eigh(G, 20, method="krylov", info=info, kern=K)
+    lam_a, V_a = dsvd.top_eigh(G, 20, method="cheb", info=info, kern=K)
     lam_f, V_f = dsvd.top_eigh(G, 20, method="full")
-    assert info["eig_method"] == "full" and info["eig_krylov_forecast_sweeps"] > 18
+    assert info["eig_method"] == "full" and info["eig_cheb_forecast_steps"] > 18 and info["eig_products"] <= 16
     assert torch.equal(lam_a, lam_f) and torch.equal(V_a, V_f)
 
 

@@ -28,12 +28,14 @@ known answers instead: planted damped complex exponentials, uneven sampling, noi
 """
 from __future__ import annotations
 
+import math
 from dataclasses import dataclass, field
 
 import numpy as np
 import torch
 
-__all__ = ["OptDMDResult", "trapezoidal_dmd_eigs", "optdmd", "bopdmd", "reduced_coordinates"]
+__all__ = ["OptDMDResult", "trapezoidal_dmd_eigs", "exact_dmd_eigs", "initial_eigs", "optdmd", "bopdmd",
+           "reduced_coordinates"]
 
 
 @dataclass
@@ -58,8 +60,14 @@ def reduced_coordinates(s: torch.Tensor, Vh: torch.Tensor) -> torch.Tensor:
     return (Vh * s[:, None].to(Vh.dtype)).T.contiguous()
 
 
-def _phi(alpha: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
-    return torch.exp(t[:, None] * alpha[None, :])
+def _phi(alpha: torch.Tensor, t: torch.Tensor, dtype: torch.dtype | None = None) -> torch.Tensor:
+    """Phi_ij = exp(alpha_j t_i).  The exponent is always formed in complex128 -- |alpha| t reaches
+    ~1.4e4 rad over a year of hourly snapshots at 6 cycles / day, which fp32 would carry to 1e-3 rad
+    only -- and the result rounded once to the working dtype."""
+    out = dtype or alpha.dtype
+    a = alpha.to(torch.complex128)
+    tt = (t.real if t.is_complex() else t).to(torch.float64)
+    return torch.exp(tt[:, None] * a[None, :]).to(out)
 
 
 def trapezoidal_dmd_eigs(H: torch.Tensor, t: torch.Tensor, r: int) -> torch.Tensor:
@@ -76,9 +84,41 @@ def trapezoidal_dmd_eigs(H: torch.Tensor, t: torch.Tensor, r: int) -> torch.Tens
     return torch.linalg.eigvals(At)
 
 
-def _project(alpha, t, H, rank_tol=1e-12):
-    """B(alpha), residual and the SVD pieces of Phi(alpha)."""
-    Phi = _phi(alpha, t)
+def exact_dmd_eigs(H: torch.Tensor, dt: float, r: int) -> torch.Tensor:
+    """Continuous-time eigenvalues log(mu) / dt of the rank-r exact DMD operator h_{i+1} = A h_i
+    (uniform sampling).  The trapezoidal rule sees mu through the bilinear map
+    lambda = (2 / dt) (mu - 1) / (mu + 1): at omega dt = pi / 2 (6 cycles / day, hourly data) that
+    is 27 % off in frequency, far outside the basin of the optimisation (its width is ~1 / T), so
+    on uniformly sampled data the one-step operator itself is used."""
+    X1, X2 = H[:-1].T, H[1:].T
+    U, S, Vh = torch.linalg.svd(X1, full_matrices=False)
+    r = min(r, int((S > S[0] * 1e-12).sum()))
+    U, S, Vh = U[:, :r], S[:r], Vh[:r]
+    At = U.conj().T @ X2 @ Vh.conj().T / S[None, :]
+    mu = torch.linalg.eigvals(At)
+    return torch.log(mu) / dt
+
+
+def initial_eigs(H: torch.Tensor, t: torch.Tensor, r: int) -> torch.Tensor:
+    """Cold-start eigenvalues (complex128): exact DMD when the sampling is uniform, the
+    trapezoidal-rule DMD of Askham & Kutz (section 3.3) otherwise."""
+    tr = (t.real if t.is_complex() else t).to(torch.float64)
+    dts = tr[1:] - tr[:-1]
+    dt = float(dts.mean())
+    H128 = H.to(torch.complex128)
+    if float((dts - dt).abs().max()) <= 1e-9 * abs(dt):
+        return exact_dmd_eigs(H128, dt, r)
+    return trapezoidal_dmd_eigs(H128, tr.to(torch.complex128), r)
+
+
+def _project(alpha, t, H, rank_tol=None):
+    """B(alpha), residual and the SVD pieces of Phi(alpha) (all in H's dtype; alpha complex128).
+    Returns None when Phi is not finite (a trial step into Re(alpha) t > the dtype's range)."""
+    Phi = _phi(alpha, t, H.dtype)
+    if not bool(torch.isfinite(Phi.real).all() and torch.isfinite(Phi.imag).all()):
+        return None
+    if rank_tol is None:
+        rank_tol = 1e-12 if H.dtype == torch.complex128 else 1e-6
     U, S, Vh = torch.linalg.svd(Phi, full_matrices=False)
     keep = int((S > S[0] * rank_tol).sum())
     U, S, Vh = U[:, :keep], S[:keep], Vh[:keep]
@@ -97,33 +137,40 @@ def optdmd(H: torch.Tensor, t: torch.Tensor, r: int, alpha0: torch.Tensor | None
     cdtype = torch.complex128 if H.dtype in (torch.float64, torch.complex128) else torch.complex64
     rdtype = torch.float64 if cdtype == torch.complex128 else torch.float32
     H = H.to(cdtype)
-    t = t.to(device=H.device, dtype=rdtype).to(cdtype)
-    alpha = (trapezoidal_dmd_eigs(H, t, r) if alpha0 is None else alpha0).to(cdtype)
+    t = (t.real if t.is_complex() else t).to(device=H.device, dtype=torch.float64)
+    # the parameters stay complex128 whatever the working dtype of the n x r matrices is
+    alpha = (initial_eigs(H, t, r) if alpha0 is None else alpha0).to(device=H.device, dtype=torch.complex128)
     r = alpha.numel()
+    tw = t.to(rdtype).to(cdtype)
     normH = torch.linalg.norm(H)
     lam = float(init_lambda)
 
-    Phi, U, S, Vh, B, R = _project(alpha, t, H)
+    pieces = _project(alpha, t, H)
+    if pieces is None:
+        raise ValueError("optdmd: exp(alpha0 * t) is not finite in the working dtype")
+    Phi, U, S, Vh, B, R = pieces
     err = float(torch.linalg.norm(R) / normH)
     n_iter, converged = 0, err < tol
     errs = [err]
     while n_iter < maxiter and not converged:
         n_iter += 1
-        W = t[:, None] * Phi
+        W = tw[:, None] * Phi
         PW = W - U @ (U.conj().T @ W)
         C = W.conj().T @ R                                           # (r, n_s)
         A1 = (PW.conj().T @ PW) * (B.conj() @ B.T)
         Sinv2V = Vh / (S[:, None].to(cdtype) ** 2)                    # S^-2 Vh
         A2 = (Vh.conj().T @ Sinv2V) * (C.conj() @ C.T)
-        JtJ = A1 + A2
-        g = (C * B.conj()).sum(dim=1)
-        dg = torch.diagonal(JtJ).real.clamp_min(1e-300).to(cdtype)
+        JtJ = (A1 + A2).to(torch.complex128)
+        g = (C * B.conj()).sum(dim=1).to(torch.complex128)
+        dg = torch.diagonal(JtJ).real.clamp_min(1e-300).to(torch.complex128)
 
         def trial(lmb):
             M = JtJ + lmb * torch.diag(dg)
             delta = torch.linalg.solve(M, g)
             a_new = alpha + delta
             pieces = _project(a_new, t, H)
+            if pieces is None or not bool(torch.isfinite(pieces[5].real).all()):
+                return a_new, None, math.inf
             return a_new, pieces, float(torch.linalg.norm(pieces[5]) / normH)
 
         a_new, pieces, e_new = trial(lam)
@@ -146,6 +193,7 @@ def optdmd(H: torch.Tensor, t: torch.Tensor, r: int, alpha0: torch.Tensor | None
             converged = True
         elif gain < eps_stall * max(err, 1e-300):
             break
+    alpha = alpha.to(cdtype)
     amp = torch.linalg.norm(B, dim=1)
     modes = (B / amp[:, None].clamp_min(1e-300).to(cdtype)).T.contiguous()
     order = torch.argsort(-amp)
@@ -188,8 +236,7 @@ def bopdmd(H: torch.Tensor, t: torch.Tensor, r: int, num_trials: int = 0, trial_
     mean = A.mean(dim=0)
     std = torch.sqrt(((A - mean).abs() ** 2).mean(dim=0))
     cdtype = mean.dtype
-    tt = t.to(device=H.device, dtype=std.dtype).to(cdtype)
-    _, _, _, _, B, R = _project(mean, tt, H.to(cdtype))
+    _, _, _, _, B, R = _project(mean.to(torch.complex128), t.to(H.device), H.to(cdtype))
     amp = torch.linalg.norm(B, dim=1)
     modes = (B / amp[:, None].clamp_min(1e-300).to(cdtype)).T.contiguous()
     order = torch.argsort(-amp)

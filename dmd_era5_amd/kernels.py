@@ -77,6 +77,16 @@ class HipKernels:
             self._ws[key] = ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=device)
         return ws
 
+    def release_workspace(self) -> int:
+        """Drop the cached partial-tile workspaces (K1 / K3: 128 KB per (row block, K-split, tile)
+        of a launch -- 10.1 GB for cfg2's Gram, 19 GB for a cfg3 shard; they are kept between calls
+        because re-allocating them costs more than the eigen stage).  Callers that are about to
+        fill the HBM with something else (main() before a larger slice, the 227 GB cfg4 matrix)
+        call this first.  Returns the number of bytes released."""
+        n = sum(int(w.numel()) for w in self._ws.values())
+        self._ws.clear()
+        return n
+
     # -- K1 -----------------------------------------------------------------
     def syrk(self, Xt: torch.Tensor, want32: bool = False, out: torch.Tensor | None = None):
         """G = X^T X (fp64, both triangles).  Xt: (n, m) fp32.  -> G64 [, G32].

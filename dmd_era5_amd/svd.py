@@ -314,6 +314,11 @@ def top_eigh(G: torch.Tensor, l: int, method: str = "auto", tol: float = 1e-9,
         Qn = S @ Z
         GQn = GS @ Z
         res = torch.linalg.vector_norm(GQn - Qn * th, dim=0) / th[0].abs().clamp_min(1e-300)
+        # Pairs at the rounding floor of G (theta_j < 8 tol theta_1: G is a sum of fp32 products,
+        # its noise "eigenvalues" are of that size and have no gaps to converge in) count as
+        # converged: svd_snapshots re-derives such directions from X itself (its polish step
+        # triggers at lambda_k < 1e-7 lambda_1).
+        res = torch.where(th > 8.0 * tol * th[0].abs(), res, torch.zeros_like(res))
         return th, Qn, GQn, res
 
     def done(th, Qn, res, how, it):
@@ -392,9 +397,17 @@ def top_eigh(G: torch.Tensor, l: int, method: str = "auto", tol: float = 1e-9,
             order += [roots[lo]] if lo == hi else [roots[lo], roots[hi]]
             lo, hi = lo + 1, hi - 1
         for i, r_i in enumerate(order):
-            # one CholeskyQR round between the factors (conditioning control), two before the
-            # Rayleigh-Ritz step (an orthonormal basis)
-            Q = _orth(torch.addmm(Q, G, Q, beta=-r_i), rounds=2 if i == deg - 1 else 1)
+            # one CholeskyQR round after every second factor (conditioning control: a factor
+            # stretches the block by at most (lambda_1 - r) / (theta_b - r) ~ 1e6, and what two
+            # of them add along the leading eigenvectors, ~1e-16 x 1e8, the round removes), two
+            # rounds before the Rayleigh-Ritz step (an orthonormal basis)
+            Q = torch.addmm(Q, G, Q, beta=-r_i)
+            if i == deg - 1:
+                Q = _orth(Q)
+            elif i % 2 == 1:
+                Q = _orth(Q, rounds=1)
+            else:
+                Q = Q / torch.linalg.vector_norm(Q, dim=0, keepdim=True).clamp_min(1e-300)
         Y = G @ Q
         products += deg + 1
         spent += deg

@@ -110,3 +110,64 @@ def test_cfg5_shape_on_device():
     assert res.eigs.is_cuda
     assert _err(res.eigs.cpu(), alpha) < 1e-5
     assert res.rel_error < 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,tol_eig", [(torch.complex64, 5e-5), (torch.complex128, 1e-5)])
+def test_cfg5_rank200_cold_start(dtype, tol_eig):
+    """BASELINE config 5 at its stated size: n = 8760 hourly snapshots (t in days), rank-200
+    reduced coordinates, complex64 ("fp32") and complex128, COLD start: the initial eigenvalues
+    are the engine's own (exact DMD of the uniformly sampled data; nothing taken from the truth),
+    and with 1 % noise they are off by ~1e-2 rad / day -- the fit has to do the work.
+    100 planted conjugate pairs, periods from 4 hours to 50 days, e-folding times 1 to 27 years.
+    Asserted: the cold start is off by > 1e-3, every planted eigenvalue is then found to tol_eig
+    (max |d alpha|, rad / day), the residual falls to the noise level, the error history never
+    rises.  (CPU rehearsal at n = 4000, r = 60: 7e-3 -> 7e-7 (complex128) / 2e-6 (complex64).)"""
+    rs = np.random.RandomState(0)
+    r, n = 200, 8760
+    t = np.arange(n) / 24.0
+    freq = np.sort(rs.uniform(0.02, 6.0, r // 2))
+    alpha = -rs.uniform(1e-4, 3e-3, r // 2) + 1j * 2 * np.pi * freq
+    alpha = np.concatenate([alpha, alpha.conj()])
+    modes = rs.standard_normal((r, r)) + 1j * rs.standard_normal((r, r))
+    clean = np.exp(np.outer(t, alpha)) @ modes
+    H = clean + 1e-2 * rs.standard_normal((n, r))
+    Hd = torch.from_numpy(H).cuda().to(dtype)
+    td = torch.from_numpy(t).cuda()
+    a0 = bop.initial_eigs(Hd, td, r)
+    e0 = _err(a0.cpu(), alpha)
+    assert e0 > 1e-3, e0
+    res = bop.optdmd(Hd, td, r, tol=1e-9, maxiter=40)
+    assert res.eigs.is_cuda and res.eigs.dtype == dtype and res.eigs.numel() == r
+    e1 = _err(res.eigs.cpu().to(torch.complex128), alpha)
+    assert e1 < tol_eig and e1 < 1e-2 * e0, (e0, e1, res.info["errors"])
+    noise_level = 1e-2 * np.sqrt(n * r) / np.linalg.norm(clean)
+    assert res.rel_error < 1.05 * noise_level, (res.rel_error, noise_level)
+    errs = res.info["errors"]
+    assert all(b <= a for a, b in zip(errs, errs[1:]))
+
+
+def test_cold_start_uses_exact_dmd_on_uniform_sampling_and_trapezoid_otherwise():
+    t = torch.linspace(0, 6, 300, dtype=torch.float64)
+    H, _ = _signal(t.numpy())
+    a_uniform = bop.initial_eigs(H, t, 6)
+    assert a_uniform.dtype == torch.complex128 and _err(a_uniform, ALPHA) < 1e-8     # noise-free: exact
+    a_trap = bop.trapezoidal_dmd_eigs(H, t.to(H.dtype), 6)
+    assert _err(a_trap, ALPHA) > 1e-3                                                # the bilinear warp
+    tj = t.clone()
+    tj[1:-1] += 1e-3 * torch.from_numpy(np.random.RandomState(0).standard_normal(298))
+    Hj, _ = _signal(tj.numpy())
+    assert torch.allclose(bop.initial_eigs(Hj, tj, 6), bop.trapezoidal_dmd_eigs(Hj, tj.to(Hj.dtype), 6))
+
+
+def test_trial_steps_into_overflow_are_rejected_not_fatal():
+    """complex64 over a long record: a Levenberg-Marquardt trial with Re(alpha) t beyond fp32's
+    range must count as a failed trial (lambda goes up), not end in NaNs inside the SVD."""
+    t = torch.linspace(0, 400, 2000, dtype=torch.float64)
+    alpha = np.array([-0.001 + 0.9j, -0.001 - 0.9j, -0.002 + 0.31j, -0.002 - 0.31j])
+    H, _ = _signal(t.numpy(), n_s=6, alpha=alpha, noise=1e-3, seed=3)
+    start = torch.from_numpy(alpha + np.array([0.3, 0.3, 0.25, 0.25]))    # e^{120}: overflows fp32
+    with pytest.raises(ValueError, match="not finite"):
+        bop.optdmd(H.to(torch.complex64), t, 4, alpha0=start)
+    res = bop.optdmd(H.to(torch.complex64), t, 4, alpha0=torch.from_numpy(alpha * (1 + 2e-3)), maxiter=30)
+    assert np.isfinite(res.rel_error) and _err(res.eigs.to(torch.complex128), alpha) < 1e-4

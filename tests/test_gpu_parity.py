@@ -427,6 +427,103 @@ def test_cfg4_shape_randomized_properties(K, k):
     assert float((UtU - eye).abs().max()) < 2e-5
 
 
+def _full_size_checks(blocks, res, r, n, tol_u=2e-5, rel_sj=1e-4):
+    """Size-independent properties of a rank-r SVD of a resident row-blocked matrix, evaluated
+    with fp64 torch products one row block at a time: s non-increasing, V V^T = I (1e-10),
+    U^T U = I, X^T u_j = s_j v_j (1e-6 s_1: fp32 storage of X and U; rel_sj s_j)."""
+    s, Vh, Ut = res.s, res.Vh, res.Ut
+    assert bool((s[:-1] >= s[1:]).all())
+    eye = torch.eye(r, dtype=torch.float64, device="cuda")
+    assert float((Vh @ Vh.T - eye).abs().max()) < 1e-10
+    UtU = torch.zeros((r, r), dtype=torch.float64, device="cuda")
+    XtU = torch.zeros((n, r), dtype=torch.float64, device="cuda")
+    r0 = 0
+    for B in blocks:
+        Ub = Ut[:, r0:r0 + B.shape[1]].double()
+        UtU += Ub @ Ub.T
+        step = max(1, min(n, (1 << 27) // max(1, B.shape[1])))      # <= 1 GiB of fp64 copy at a time
+        for j0 in range(0, n, step):
+            XtU[j0:j0 + step] += B[j0:j0 + step].double() @ Ub.T
+        r0 += B.shape[1]
+    assert float((UtU - eye).abs().max()) < tol_u
+    err = (XtU - (Vh.T * s)).norm(dim=0)
+    assert float((err / s[0]).max()) < 1e-6
+    if rel_sj is not None:
+        assert float((err / s).max()) < rel_sj
+    return err
+
+
+def test_cfg2_full_size_gap_free_spectrum(K):
+    """cfg2's size with the spectrum ERA5 anomalies actually have: sigma_i ~ 1/i over all 8760
+    columns, no gap anywhere (bench.make_powerlaw_blocks).  The power steps of the eigen stage
+    cannot finish here; the Chebyshev-filtered iteration must, without the 0.8 s library syevd.
+    Same size-independent checks as the planted-rank test, plus the spectrum itself:
+    s_i = sigma_i sqrt(m) within the Marchenko-Pastur edge factors 1 +- sqrt(n/m) (9 %)."""
+    import bench
+    from dmd_era5_amd import svd as dsvd
+
+    torch.cuda.empty_cache()
+    free, _ = torch.cuda.mem_get_info()
+    if free < 60 * 2**30:
+        pytest.skip("needs ~45 GB of HBM")
+    m, n, r, _ = bench.WORKLOADS["cfg2"]
+    blocks = bench.make_powerlaw_blocks(m, n, 1234, torch.device("cuda"))
+    for B in blocks:
+        K.row_center_scale_(B, False)
+    res = dsvd.svd_snapshots(blocks, r, kern=K, timings=True)
+    assert res.Ut.shape == (r, m) and res.Vh.shape == (r, n) and res.s.shape == (r,)
+    assert res.info["eig_method"] in ("cheb", "power"), res.info     # never the full solver at n = 8760
+    assert res.info["eig_products"] <= 24
+    expect = 100.0 / np.arange(1, r + 1) * np.sqrt(float(m))
+    ratio = res.s.cpu().numpy() / expect
+    assert np.all(np.abs(ratio - 1.0) < 0.12), ratio
+    _full_size_checks(blocks, res, r, n)
+    # the eigen stage stays a small share of the step (the Gram is ~0.57 s)
+    res = dsvd.svd_snapshots(blocks, r, kern=K, timings=True)
+    assert res.info["t_eig"] < 0.08 * res.info["t_total"], res.info
+
+
+def test_cfg4_full_size_randomized(K):
+    """BASELINE config 4 at its stated size: 15 573 600 x 3653 fp32 = 227.6 GB resident on one
+    MI355X (119 row blocks; n % 4 != 0), randomized SVD with oversample 20 and 2 power
+    iterations, k = 50 (l = 70) and k = 200 (l = 220).  Properties: U^T U = I, V V^T = I,
+    s non-increasing, X^T u_j = s_j v_j, and the planted part of the spectrum (64 terms
+    100 * 0.9^i * sqrt(m n), 5 %: the Gaussian factors are orthogonal to O(n^-1/2)) -- the
+    leading 40 also against the method of snapshots on the same resident matrix."""
+    import bench
+    from dmd_era5_amd import svd as dsvd
+
+    K.release_workspace()
+    torch.cuda.empty_cache()
+    free, _ = torch.cuda.mem_get_info()
+    if free < 253 * 2**30:
+        pytest.skip(f"needs ~270 GB (252 GiB) of free HBM, {free / 2**30:.0f} GiB available")
+    m, n = 15 * 721 * 1440, 3653
+    blocks = bench.make_snapshot_blocks(m, n, 99, torch.device("cuda"))
+    for B in blocks:
+        K.row_center_scale_(B, False)
+    planted = 100.0 * 0.9 ** np.arange(64) * np.sqrt(float(m) * n)
+    st = dsvd.svd_snapshots(blocks, 40, kern=K)
+    s_ref = st.s.clone()
+    del st
+    for k in (50, 200):
+        rr = dsvd.svd_randomized(blocks, k, n_oversamples=20, n_iter=2, random_state=0, kern=K)
+        assert rr.Ut.shape == (k, m) and rr.Vh.shape == (k, n) and rr.info["l"] == k + 20
+        assert rr.info["passes_over_X"] == 6 and rr.info["row_blocks"] == len(blocks)
+        lead = min(k, 60)
+        assert np.all(np.abs(rr.s[:lead].cpu().numpy() / planted[:lead] - 1.0) < 0.05)
+        assert float(((rr.s[:40] - s_ref).abs() / s_ref).max()) < 1e-5
+        # beyond the planted rank (k = 200) the wanted values sit in the noise bulk, where two
+        # power iterations resolve s but not individual vectors: the relation is asserted
+        # against s_1 only there
+        _full_size_checks(blocks, rr, k, n, rel_sj=1e-3 if k == 50 else None)
+        del rr
+        torch.cuda.empty_cache()
+    del blocks
+    K.release_workspace()
+    torch.cuda.empty_cache()
+
+
 # ---------------------------------------------------------------- K7 small eigensolver
 @pytest.mark.parametrize("n", [1, 2, 3, 17, 62, 77, 96])
 def test_eigh_small_matches_lapack(K, n):

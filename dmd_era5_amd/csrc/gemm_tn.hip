@@ -89,6 +89,9 @@ struct TnBatch {
   int unit_begin[MAXB + 1];
   int slab_begin[MAXB + 1];
   int nblocks;
+  // measurement aid (dmdx_set_clock_probe; null on the product path): every workgroup adds the
+  // core-clock cycles and the 100 MHz reference ticks of its lifetime and 1 to clk[0..2]
+  unsigned long long* clk;
 };
 
 // upper-triangle tile enumeration: super-rows of SR tile rows, column-major
@@ -555,7 +558,22 @@ __global__ __launch_bounds__(NTH, 2) void syrk_batch_kernel(TnParams p, TnBatch 
   p.chunks_total = bt.chunks_total[j];
   p.chunks_per_split = bt.chunks_per_split[j];
   double* Pt = p.P + ((size_t)(bt.slab_begin[j] + split) * p.ntiles + tile) * (TM * BT);
+  // (measurement aid: two scalar clock reads around the unit, three atomics per workgroup; the
+  // sustained core clock of the launch = 100 MHz * sum(cycles) / sum(ticks))
+  unsigned long long c0 = 0, r0 = 0;
+  if (bt.clk != nullptr) {
+    c0 = __builtin_amdgcn_s_memtime();
+    r0 = __builtin_amdgcn_s_memrealtime();
+  }
   tn_unit<DMA, 0, SK>(p, split, ta * TM, tb * BT, Pt, lds);
+  if (bt.clk != nullptr) {
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) {
+      atomicAdd(&bt.clk[0], c1 - c0);
+      atomicAdd(&bt.clk[1], r1 - r0);
+      atomicAdd(&bt.clk[2], 1ull);
+    }
+  }
 }
 
 // Sum the K-splits in fp64 and scatter the tile into D (row-major view:
@@ -752,6 +770,8 @@ size_t batch_group_ws(const int64_t* K, int nb, int64_t nrow, int64_t ncol, int 
   return slabs * (size_t)pl.ntiles * pl.tm * BT * sizeof(double);
 }
 
+unsigned long long* g_clock_probe = nullptr;  // dmdx_set_clock_probe (measurement aid)
+
 int run_batch(const float* const* A, const int64_t* lda, const float* const* B, const int64_t* ldb,
               const int64_t* K, int nblocks, int64_t nrow, int64_t ncol, int syrk, double* D64, int64_t ld64,
               float* D32, int64_t ld32, int accumulate, void* ws, size_t ws_bytes, hipStream_t stream) {
@@ -793,6 +813,7 @@ int run_batch(const float* const* A, const int64_t* lda, const float* const* B, 
     bt.unit_begin[nb] = units;
     bt.slab_begin[nb] = slabs;
     bt.nblocks = nb;
+    bt.clk = g_clock_probe;
     p.nrow = (int)nrow;
     p.ncol = (int)ncol;
     p.ntr = pl.ntr; p.ntc = pl.ntc; p.ntiles = pl.ntiles; p.syrk = pl.syrk;
@@ -835,6 +856,11 @@ int dmdx_debug_read_stamps(unsigned long long* out8, int reset) {
   return (int)e;
 }
 #endif
+
+int dmdx_set_clock_probe(unsigned long long* dev_counters3) {
+  g_clock_probe = dev_counters3;
+  return 0;
+}
 
 size_t dmdx_syrk_workspace_bytes(int64_t m, int64_t n) {
   if (m < 0 || n <= 0) return 0;

@@ -299,6 +299,64 @@ class HipKernels:
         return w, V
 
 
+    # -- K8 -----------------------------------------------------------------
+    def symm_skinny(self, G: torch.Tensor, Q: torch.Tensor, shift: float = 0.0,
+                    out: torch.Tensor | None = None) -> torch.Tensor:
+        """Y = G Q - shift Q for a SYMMETRIC fp64 device matrix G (n, n) and a block Q (n, b):
+        the products of the top-eigenpair solver (fp64 MFMA, one pass over G).  Shapes the
+        kernel's 16-byte fragment loads cannot take (odd n or b, unaligned views) go through
+        the library GEMM -- same result, ~1 ms at n = 8760."""
+        if G.dtype != torch.float64 or Q.dtype != torch.float64 or G.dim() != 2 or Q.dim() != 2 \
+                or G.shape[0] != G.shape[1] or Q.shape[0] != G.shape[0] or not (G.is_cuda and Q.is_cuda):
+            raise _lib.DmdxError("symm_skinny: G (n, n) and Q (n, b) must be fp64 device matrices")
+        n, b = Q.shape
+        ok = (n >= 2 and b >= 2 and n % 2 == 0 and b % 2 == 0 and G.stride(1) == 1 and Q.stride(1) == 1
+              and G.stride(0) % 2 == 0 and Q.stride(0) % 2 == 0 and G.data_ptr() % 16 == 0
+              and Q.data_ptr() % 16 == 0 and b <= 4096)
+        if not ok:
+            Y = torch.addmm(Q, G, Q, beta=-float(shift)) if shift != 0.0 else G @ Q
+            if out is not None:
+                out.copy_(Y)
+                return out
+            return Y
+        Y = out if out is not None else torch.empty((n, b), dtype=torch.float64, device=G.device)
+        if Y.shape != (n, b) or Y.dtype != torch.float64 or Y.stride(1) != 1 or Y.data_ptr() == Q.data_ptr():
+            raise _lib.DmdxError("symm_skinny: out must be an (n, b) fp64 tensor that does not alias Q")
+        ws = self._workspace(G.device, self._lib.dmdx_symm_skinny_workspace_bytes(n, b))
+        rc = self._timed("symm_skinny", (n, b), lambda: self._lib.dmdx_symm_skinny_f64(
+            _ptr(G), n, G.stride(0), _ptr(Q), Q.stride(0), b, float(shift), _ptr(Y), Y.stride(0),
+            _ptr(ws), ws.numel(), self._stream()
+        ))
+        _lib.check(rc, "dmdx_symm_skinny_f64")
+        return Y
+
+    # -- packed upper triangle (the Gram all-reduce of the row-sharded path) -----
+    def pack_triu(self, A: torch.Tensor) -> torch.Tensor:
+        """Upper triangle of a square fp64 device matrix, row by row: n (n + 1) / 2 doubles."""
+        if A.dtype != torch.float64 or A.dim() != 2 or A.shape[0] != A.shape[1] or not A.is_cuda or A.stride(1) != 1:
+            raise _lib.DmdxError("pack_triu: expected a square fp64 device matrix with inner stride 1")
+        n = A.shape[0]
+        packed = torch.empty(n * (n + 1) // 2, dtype=torch.float64, device=A.device)
+        _lib.check(self._lib.dmdx_pack_triu_f64(_ptr(A), n, A.stride(0), _ptr(packed), self._stream()),
+                   "dmdx_pack_triu_f64")
+        return packed
+
+    def unpack_triu(self, packed: torch.Tensor, n: int, out: torch.Tensor | None = None) -> torch.Tensor:
+        """The symmetric (n, n) matrix whose upper triangle ``packed`` holds (both triangles written)."""
+        if packed.dtype != torch.float64 or packed.numel() != n * (n + 1) // 2 or not packed.is_cuda:
+            raise _lib.DmdxError("unpack_triu: packed must hold n (n + 1) / 2 fp64 device values")
+        A = out if out is not None else torch.empty((n, n), dtype=torch.float64, device=packed.device)
+        _lib.check(self._lib.dmdx_unpack_triu_f64(_ptr(packed.contiguous()), n, _ptr(A), A.stride(0), self._stream()),
+                   "dmdx_unpack_triu_f64")
+        return A
+
+    # -- measurement aid ------------------------------------------------------
+    def clock_probe(self, counters: torch.Tensor | None) -> None:
+        """Switch the per-workgroup clock stamps of the batched Gram launch on (3 zeroed device
+        uint64 / int64) or off (None): bench.py's calibration block only."""
+        _lib.check(self._lib.dmdx_set_clock_probe(_ptr(counters)), "dmdx_set_clock_probe")
+
+
 _default: HipKernels | None = None
 
 

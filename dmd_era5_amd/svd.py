@@ -102,8 +102,17 @@ class TorchDistComm(Comm):
 
     def broadcast_(self, *tensors: torch.Tensor):
         if self.world_size > 1:
-            for t in tensors:
-                self._dist.broadcast(t, src=0, group=self._group)
+            if len(tensors) > 1 and len({(t.dtype, t.device) for t in tensors}) == 1:
+                # ONE collective for the lot (eigenvalues + eigenvectors, rotation + values)
+                flat = torch.cat([t.reshape(-1) for t in tensors])
+                self._dist.broadcast(flat, src=0, group=self._group)
+                off = 0
+                for t in tensors:
+                    t.copy_(flat[off:off + t.numel()].view(t.shape))
+                    off += t.numel()
+            else:
+                for t in tensors:
+                    self._dist.broadcast(t, src=0, group=self._group)
         return tensors if len(tensors) != 1 else tensors[0]
 
     def gather_to_root(self, t: torch.Tensor) -> list[torch.Tensor] | None:
@@ -299,10 +308,18 @@ def top_eigh(G: torch.Tensor, l: int, method: str = "auto", tol: float = 1e-9,
     if method != "cheb":
         raise ValueError(f"top_eigh: unknown method {method!r}")
 
-    b = min(n // 3, l + max(8, l // 4))
+    b = min(n // 3, l + max(8, l // 4) + 1) & ~1    # even widths: K8's 16-byte fragment loads
     gen = torch.Generator(device=G.device).manual_seed(1234)  # (a host draw + upload costs 7 ms)
     Q = torch.randn((n, b), dtype=torch.float64, generator=gen, device=G.device)
-    Q = _orth(G @ Q)
+    k8 = getattr(kern, "symm_skinny", None)
+
+    def gq(Qb, shift: float = 0.0):
+        """G Qb - shift Qb: K8 (fp64 MFMA, one pass over G) when the provider has it."""
+        if k8 is not None:
+            return k8(G, Qb, shift)
+        return torch.addmm(Qb, G, Qb, beta=-shift) if shift != 0.0 else G @ Qb
+
+    Q = _orth(gq(Q))
     products = 1
 
     def ritz(S, GS):
@@ -337,8 +354,8 @@ def top_eigh(G: torch.Tensor, l: int, method: str = "auto", tol: float = 1e-9,
     # and each step gains ~3 digits) this reaches the tolerance after 3 products; otherwise its
     # Ritz vectors are the start of the filtered iteration.
     for it in range(2):
-        Q = _orth(G @ Q)
-        Y = G @ Q
+        Q = _orth(gq(Q))
+        Y = gq(Q)
         products += 2
         th, Q, GQ, resv = ritz(Q, Y)
         res = float(resv[:l].max())
@@ -354,13 +371,13 @@ def top_eigh(G: torch.Tensor, l: int, method: str = "auto", tol: float = 1e-9,
     # Widen the block for the filter (its growth rate per product is set by lambda_l / lambda_{b+1}):
     # 2 l columns, the new ones G-multiplied noise orthogonalised against the Ritz vectors; G Q of
     # the old ones is known from the Rayleigh-Ritz step, so this costs two products.
-    b2 = min(n // 3, max(b, 2 * l))
+    b2 = min(n // 3, max(b, 2 * l)) & ~1
     if b2 > b:
-        W = G @ torch.randn((n, b2 - b), dtype=torch.float64, generator=gen, device=G.device)
+        W = gq(torch.randn((n, b2 - b), dtype=torch.float64, generator=gen, device=G.device))
         for _ in range(2):
             W = W - Q @ (Q.T @ W)
         W = _orth(W)
-        th, Q, GQ, resv = ritz(torch.cat([Q, W], dim=1), torch.cat([GQ, G @ W], dim=1))
+        th, Q, GQ, resv = ritz(torch.cat([Q, W], dim=1), torch.cat([GQ, gq(W)], dim=1))
         products += 2
         b = b2
         res = float(resv[:l].max())
@@ -401,14 +418,14 @@ def top_eigh(G: torch.Tensor, l: int, method: str = "auto", tol: float = 1e-9,
             # stretches the block by at most (lambda_1 - r) / (theta_b - r) ~ 1e6, and what two
             # of them add along the leading eigenvectors, ~1e-16 x 1e8, the round removes), two
             # rounds before the Rayleigh-Ritz step (an orthonormal basis)
-            Q = torch.addmm(Q, G, Q, beta=-r_i)
+            Q = gq(Q, r_i)
             if i == deg - 1:
                 Q = _orth(Q)
             elif i % 2 == 1:
                 Q = _orth(Q, rounds=1)
             else:
                 Q = Q / torch.linalg.vector_norm(Q, dim=0, keepdim=True).clamp_min(1e-300)
-        Y = G @ Q
+        Y = gq(Q)
         products += deg + 1
         spent += deg
         th, Q, GQ, resv = ritz(Q, Y)
@@ -465,7 +482,14 @@ def as_blocks(Xt) -> list[torch.Tensor]:
 
 
 def _gram_blocks(blocks, kern, comm: Comm) -> torch.Tensor:
+    """G = sum over the local row blocks and over the ranks of X_b^T X_b (fp64, both triangles).
+    Across ranks only the upper triangle travels: n (n + 1) / 2 doubles, 307 MB instead of 614 MB
+    at n = 8760 (the one large exchange of the row-sharded method of snapshots)."""
     G = kern.syrk_blocks(blocks) if len(blocks) > 1 else kern.syrk(blocks[0])
+    n = G.shape[0]
+    if comm.world_size > 1 and n >= 64 and hasattr(kern, "pack_triu"):
+        packed = comm.allreduce_sum_(kern.pack_triu(G))
+        return kern.unpack_triu(packed, n, out=G)
     return comm.allreduce_sum_(G)
 
 
@@ -543,57 +567,69 @@ def _sync_time(device) -> float:
 # ---------------------------------------------------------------------------
 # "standard": method of snapshots
 # ---------------------------------------------------------------------------
-def _magnitude_guard(fn):
-    """Entry-point decorator: data far outside the fp32 comfort zone (|x| ~ 1e20: the squares
-    overflow; ~1e-20: they underflow) are scaled in place by a power of two (exact), factored,
-    and scaled back; s is scaled accordingly.  LAPACK's gesdd does the same (xLASCL).  The
-    magnitude is read from up to 2048 rows of every block."""
+def _shard_stats(blocks, comm: Comm, delay: int, with_mean: bool) -> dict:
+    """What the drivers need to know about the matrix as a whole, from ONE exchange: the largest
+    magnitude (for the power-of-two rescaling), the energy of the per-row time mean against the
+    energy around it (un-centred fields such as temperature ~ 280 K + O(10) K anomalies), both read
+    from up to 2048 rows of every block, and the global number of embedded rows."""
+    dev = blocks[0].device
+    v = torch.zeros(4, dtype=torch.float64, device=dev)
+    v[0] = torch.stack([B[:, : min(2048, B.shape[1])].abs().max() for B in blocks]).max().double()
+    if with_mean:
+        for B in blocks:
+            var, mean = torch.var_mean(B[:, : min(2048, B.shape[1])].double(), dim=0, unbiased=False)
+            v[1] += (mean * mean).sum()
+            v[2] += var.sum()
+    v[3] = float(sum(B.shape[1] for B in blocks) * delay)
+    if comm.world_size > 1:
+        allv = torch.stack(comm.allgather(v))
+        v = torch.cat([allv[:, :1].max(dim=0).values, allv[:, 1:].sum(dim=0)])
+    amax, mean2, var, rows = v.tolist()
+    return {"amax": amax, "mean2": mean2, "var": var, "rows": int(round(rows))}
+
+
+def _magnitude_guard(with_mean: bool):
+    """Entry-point decorator: gathers the global facts about the matrix (:func:`_shard_stats`, one
+    collective) and passes them on as ``_stats``; data far outside the fp32 comfort zone
+    (|x| ~ 1e20: the squares overflow; ~1e-20: they underflow) are scaled in place by a power of
+    two (exact), factored, and scaled back; s is scaled accordingly.  LAPACK's gesdd does the same
+    (xLASCL)."""
     import functools
 
-    @functools.wraps(fn)
-    def wrapper(Xt, *args, **kwargs):
-        blocks = as_blocks(Xt)
-        comm = kwargs.get("comm") or Comm()
-        amax = torch.stack([B[:, : min(2048, B.shape[1])].abs().max() for B in blocks]).max().double().reshape(1)
-        if comm.world_size > 1:
-            amax = torch.stack(comm.allgather(amax)).max().reshape(1)
-        a = float(amax[0])
-        if not (math.isfinite(a) and a > 0.0) or 2.0 ** -40 <= a <= 2.0 ** 40:
-            return fn(blocks, *args, **kwargs)
-        c = 2.0 ** (-round(math.log2(a)))
-        for B in blocks:
-            B *= c
-        try:
-            res = fn(blocks, *args, **kwargs)
-        finally:
+    def deco(fn):
+        @functools.wraps(fn)
+        def wrapper(Xt, *args, **kwargs):
+            blocks = as_blocks(Xt)
+            comm = kwargs.get("comm") or Comm()
+            delay = kwargs.get("delay", args[1] if len(args) > 1 else 1)
+            want_mean = with_mean and kwargs.get("deflate_mean") is None
+            stats = _shard_stats(blocks, comm, int(delay), want_mean)
+            kwargs["_stats"] = stats
+            a = stats["amax"]
+            if not (math.isfinite(a) and a > 0.0) or 2.0 ** -40 <= a <= 2.0 ** 40:
+                return fn(blocks, *args, **kwargs)
+            c = 2.0 ** (-round(math.log2(a)))
             for B in blocks:
-                B *= 1.0 / c
-        res.s = res.s / c
-        res.info["rescaled_by"] = c
-        return res
+                B *= c
+            try:
+                res = fn(blocks, *args, **kwargs)
+            finally:
+                for B in blocks:
+                    B *= 1.0 / c
+            res.s = res.s / c
+            res.info["rescaled_by"] = c
+            return res
 
-    return wrapper
+        return wrapper
 
-
-def _time_mean_dominates(blocks, comm: Comm) -> bool:
-    """Does the per-row time mean carry > 99 % of the energy of X (un-centred fields such as
-    temperature ~ 280 K + O(10) K anomalies)?  Estimated on up to 2048 rows of every block.
-    (Below that ratio s_1 / s_2 stays in the hundreds, which the plain Gram route resolves; and
-    the deflation's Schur complement is exact only up to lambda_2 / lambda_1.)"""
-    acc = torch.zeros(2, dtype=torch.float64, device=blocks[0].device)
-    for B in blocks:
-        var, mean = torch.var_mean(B[:, : min(2048, B.shape[1])].double(), dim=0, unbiased=False)
-        acc[0] += (mean * mean).sum()
-        acc[1] += var.sum()
-    comm.allreduce_sum_(acc)
-    return bool(acc[0] > 100.0 * acc[1])
+    return deco
 
 
-@_magnitude_guard
+@_magnitude_guard(with_mean=True)
 def svd_snapshots(Xt, n_components: int, delay: int = 1, oversample: int | None = None,
                   refine: bool = True, flip_sign: bool = True, comm: Comm | None = None,
                   kern=None, eig_method: str = "auto", timings: bool = False,
-                  deflate_mean: bool | None = None) -> SvdResult:
+                  deflate_mean: bool | None = None, _stats: dict | None = None) -> SvdResult:
     """Rank-k SVD of the (delay-embedded) snapshot matrix by the Gram route.
 
     Xt: (n, m_local) fp32 device tensor -- or a list of such row blocks --
@@ -619,8 +655,13 @@ def svd_snapshots(Xt, n_components: int, delay: int = 1, oversample: int | None 
     info: dict = {}
     blocks = as_blocks(Xt)
     dev = blocks[0].device
+    if _stats is None:
+        _stats = _shard_stats(blocks, comm, delay, deflate_mean is None)
     if deflate_mean is None:
-        deflate_mean = refine and blocks[0].shape[0] - delay + 1 > 2 and _time_mean_dominates(blocks, comm)
+        # > 99 % of the energy in the per-row time mean: below that ratio s_1 / s_2 stays in the
+        # hundreds, which the plain Gram route resolves (and the deflation's Schur complement is
+        # exact only up to lambda_2 / lambda_1)
+        deflate_mean = refine and blocks[0].shape[0] - delay + 1 > 2 and _stats["mean2"] > 100.0 * _stats["var"]
     t0 = _sync_time(dev) if timings else 0.0
     mus = [kern.row_center_scale_(B, False)[0] for B in blocks] if deflate_mean else None
     try:
@@ -641,11 +682,7 @@ def svd_snapshots(Xt, n_components: int, delay: int = 1, oversample: int | None 
         nd = G.shape[0]
         t1 = _sync_time(dev) if timings else 0.0
 
-        Mg = sum(B.shape[1] for B in blocks) * delay
-        if comm.world_size > 1:
-            tot = torch.tensor([Mg], dtype=torch.int64, device=dev)
-            comm.allreduce_sum_(tot)
-            Mg = int(tot.item())
+        Mg = _stats["rows"]
         k = min(n_components, nd, Mg)  # np.linalg.svd(full_matrices=False)[:k]
         p = oversample if oversample is not None else max(8, k // 4)
         l = min(nd, k + p) if refine else k
@@ -959,12 +996,12 @@ def resolve_n_iter(n_components: int, m: int, n: int, n_iter="auto") -> int:
     return int(n_iter)
 
 
-@_magnitude_guard
+@_magnitude_guard(with_mean=False)
 def svd_randomized(Xt, n_components: int, delay: int = 1, n_oversamples: int = 10,
                    n_iter="auto", power_iteration_normalizer: str = "auto",
                    omega: np.ndarray | torch.Tensor | None = None, random_state=None,
                    flip_sign: bool = True, comm: Comm | None = None, kern=None,
-                   timings: bool = False) -> SvdResult:
+                   timings: bool = False, _stats: dict | None = None) -> SvdResult:
     """Randomized SVD (Halko et al.) as sklearn runs it for m >= n.
 
     omega: optional (n_eff, k+p) test matrix; default
@@ -978,12 +1015,9 @@ def svd_randomized(Xt, n_components: int, delay: int = 1, n_oversamples: int = 1
     dev = blocks[0].device
     Eb = [embed_view(B, delay) for B in blocks]
     nd = Eb[0].shape[0]
-    M = sum(E.shape[1] for E in Eb)
-    Mg = M
-    if comm.world_size > 1:
-        tot = torch.tensor([M], dtype=torch.int64, device=dev)
-        comm.allreduce_sum_(tot)
-        Mg = int(tot.item())
+    if _stats is None:
+        _stats = _shard_stats(blocks, comm, delay, False)
+    Mg = _stats["rows"]
     if Mg < nd:
         raise ValueError("svd_randomized expects a tall matrix (space >= time); "
                          "transpose first (see svd_device)")

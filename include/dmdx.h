@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define DMDX_VERSION 100 /* 0.1.0 */
+#define DMDX_VERSION 110 /* 0.1.1 */
 
 #define DMDX_E_INVALID (-1000)  /* bad argument (shape, ld, null pointer)  */
 #define DMDX_E_WORKSPACE (-1001) /* workspace too small                      */
@@ -133,6 +133,30 @@ int dmdx_scale_columns_f32(float* Y, int64_t m, int64_t l, int64_t ldy,
 int dmdx_eigh_small_max_n(void);
 int dmdx_eigh_small_f64(const double* A, int64_t n, int64_t lda, double* w, double* V,
                         int64_t ldv, int* sweeps, void* stream);
+
+/* ---- K8: Y = G Q - shift Q, G symmetric n x n fp64, Q / Y n x b row-major (ldq, ldy) ------
+ * The products of the top-eigenpair solver on the Gram matrix (the part of np.linalg.svd,
+ * era5_svd.py:251, left once X is reduced to G): fp64 MFMA, G streamed once, Q staged in LDS,
+ * K split over workgroups with per-split partial tiles in the workspace (deterministic), summed
+ * and shifted by a second kernel.  n, b, ldg, ldq even; G, Q, workspace 16-byte aligned; only
+ * G = G^T is supported (row k of G is read as column k).  Y must not alias Q. */
+size_t dmdx_symm_skinny_workspace_bytes(int64_t n, int64_t b);
+int dmdx_symm_skinny_f64(const double* G, int64_t n, int64_t ldg, const double* Q, int64_t ldq,
+                         int64_t b, double shift, double* Y, int64_t ldy,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- upper triangle of a symmetric fp64 matrix <-> packed row by row ---------------------
+ * packed[i (2n - i + 1) / 2 + (j - i)] = A[i][j], j >= i: what the Gram all-reduce of the
+ * row-sharded path moves (n (n + 1) / 2 doubles instead of n^2).  unpack writes both triangles. */
+int dmdx_pack_triu_f64(const double* A, int64_t n, int64_t lda, double* packed, void* stream);
+int dmdx_unpack_triu_f64(const double* packed, int64_t n, double* A, int64_t lda, void* stream);
+
+/* ---- measurement aid (not on the path): sustained core clock of the Gram launches ----------
+ * While dev_counters3 (3 device uint64, caller-zeroed) is set, every workgroup of
+ * dmdx_syrk_blocks_f32 adds its core-clock cycles (s_memtime), its 100 MHz reference ticks
+ * (s_memrealtime) and 1 to it: clock = 100 MHz * [0] / [1].  NULL (the default) switches the
+ * stamps off again; bench.py's calibration block is the only caller. */
+int dmdx_set_clock_probe(unsigned long long* dev_counters3);
 
 /* ---- measurement aid (not on the path): register-only fp32 MFMA loop -----------
  * 2 workgroups of 4 waves per CU, 16 * iters v_mfma_f32_32x32x2_f32 per wave; *flops_out

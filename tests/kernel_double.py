@@ -65,6 +65,24 @@ class CpuKernelDouble:
         Yt *= alpha[:, None]
         return Yt
 
+    def symm_skinny(self, G, Q, shift=0.0, out=None):
+        Y = G @ Q - shift * Q
+        if out is not None:
+            out.copy_(Y)
+            return out
+        return Y
+
+    def pack_triu(self, A):
+        i, j = torch.triu_indices(A.shape[0], A.shape[0])
+        return A[i, j].contiguous()
+
+    def unpack_triu(self, packed, n, out=None):
+        A = out if out is not None else torch.empty((n, n), dtype=packed.dtype)
+        i, j = torch.triu_indices(n, n)
+        A[i, j] = packed
+        A[j, i] = packed
+        return A
+
     eigh_small_max_n = 96
 
     def eigh_small(self, T):

@@ -38,7 +38,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 
 def test_version_and_error_string(lib):
-    assert lib.dmdx_version() == 100
+    assert lib.dmdx_version() == 110
     assert isinstance(lib.dmdx_last_error(), bytes)
 
 

@@ -524,6 +524,52 @@ def test_cfg4_full_size_randomized(K):
     torch.cuda.empty_cache()
 
 
+# ---------------------------------------------------------------- K8 fp64 symmetric product
+@pytest.mark.parametrize("n,b,shift", [(2, 2, 0.0), (34, 2, 0.5), (256, 32, 0.0), (258, 34, -1.25), (1000, 78, 3.0),
+                                        (1500, 124, 0.0), (1024, 130, 7.5), (2050, 312, 1e3), (8760, 78, 2.0)])
+def test_symm_skinny_matches_fp64_gemm(K, n, b, shift):
+    """Y = G Q - shift Q on the fp64 MFMA path against torch's fp64 GEMM: |dY| <= 1e-13 sum|g||q|
+    (fp64 products and sums in a different order), all row / column / K-split edge cases: n not
+    a multiple of the 256-row tile or of the 32-row chunk, b not a multiple of 32, b > 128 (two
+    column passes), one and several K splits."""
+    g = torch.Generator(device="cuda").manual_seed(n * 7 + b)
+    A = torch.randn((n, n), generator=g, device="cuda", dtype=torch.float64)
+    G = A + A.T
+    Q = torch.randn((n, b), generator=g, device="cuda", dtype=torch.float64)
+    Y = K.symm_skinny(G, Q, shift)
+    ref = G @ Q - shift * Q
+    bound = 1e-13 * (G.abs() @ Q.abs() + abs(shift) * Q.abs()) + 1e-300
+    assert Y.shape == (n, b) and bool(((Y - ref).abs() <= bound).all())
+    # deterministic (per-split partial tiles, no atomics), and `out=` writes in place
+    out = torch.empty_like(Y)
+    assert K.symm_skinny(G, Q, shift, out=out) is out and torch.equal(out, Y)
+
+
+def test_symm_skinny_odd_shapes_take_the_library_path(K):
+    g = torch.Generator(device="cuda").manual_seed(5)
+    A = torch.randn((301, 301), generator=g, device="cuda", dtype=torch.float64)
+    G = A + A.T
+    Q = torch.randn((301, 77), generator=g, device="cuda", dtype=torch.float64)
+    assert torch.allclose(K.symm_skinny(G, Q, 2.0), G @ Q - 2.0 * Q, rtol=1e-12, atol=1e-10)
+    from dmd_era5_amd._lib import DmdxError
+
+    with pytest.raises(DmdxError):
+        K.symm_skinny(G.float(), Q.float())
+
+
+@pytest.mark.parametrize("n", [1, 2, 65, 300, 1031])
+def test_pack_unpack_triu_roundtrip(K, n):
+    g = torch.Generator(device="cuda").manual_seed(n)
+    A = torch.randn((n, n), generator=g, device="cuda", dtype=torch.float64)
+    S = A + A.T
+    packed = K.pack_triu(S)
+    i, j = torch.triu_indices(n, n, device="cuda")
+    assert packed.shape == (n * (n + 1) // 2,) and torch.equal(packed, S[i, j])
+    assert torch.equal(K.unpack_triu(packed, n), S)
+    # only the upper triangle of the input is read
+    assert torch.equal(K.unpack_triu(K.pack_triu(torch.triu(S)), n), S)
+
+
 # ---------------------------------------------------------------- K7 small eigensolver
 @pytest.mark.parametrize("n", [1, 2, 3, 17, 62, 77, 96])
 def test_eigh_small_matches_lapack(K, n):

@@ -1,27 +1,40 @@
 #!/usr/bin/env python3
 """Headline benchmark: rank-r SVD GB/s on the ERA5 snapshot matrix + fp32 MFMA fraction.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|small]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg3|cfg4|small]
+                    [--spectrum planted|powerlaw] [--no-hard-spectrum] [--no-cpu-baseline]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Workload (BASELINE.json configs[1] / SURVEY.md section 8d, "cfg2"): synthetic
-X = A diag(sigma) B^T + eps on the device, m = 721*1440 = 1 038 240 space points x
-n = 8760 hourly snapshots, fp32, sigma_i = 100*0.9^i (64 terms), eps ~ N(0, 0.01^2),
-Philox seed 1234 (+rank), held as 8 row blocks of 129 780 space points, row-centred
-with K5; rank-50 "standard" SVD (method of
-snapshots): Gram (K1) -> top eigenpairs (fp64) -> U = X V S^-1 (K2) -> Rayleigh-Ritz
-refinement.  A step = one full SVD with X resident in HBM.  With N > 1 every rank
-holds its own 1 038 240-row shard (weak scaling, config-3 style) and the only
-exchange is the all-reduce of the n x n Gram (+ one l x l) over RCCL.
+Workloads (BASELINE.json `configs`), all synthetic on the device, row-centred
+with K5, held as row blocks of <= 131072 space points:
+  cfg2 (default, the configuration the target is quoted on): X = A diag(sigma) B^T + eps,
+        m = 721*1440 = 1 038 240 space points x n = 8760 hourly snapshots, fp32,
+        sigma_i = 100*0.9^i (64 terms), eps ~ N(0, 0.01^2), Philox seed 1234 (+rank); rank-50
+        "standard" SVD (method of snapshots): Gram (K1) -> top eigenpairs (fp64, K8 / K7) ->
+        U = X V S^-1 (K2) -> Rayleigh-Ritz refinement.  With N > 1 every rank holds its own
+        1 038 240-row shard of ONE global matrix (weak scaling).
+  cfg3: the same generator, 1 946 700 rows per GPU, rank 200 -- at N = 8 this IS config 3
+        (15 573 600 x 8760, rank 200, row-sharded, one Gram all-reduce per step); weak scaling.
+  cfg4: 15 573 600 x 3653 in total (m / N rows per GPU: strong scaling, "1 vs 8 GPU"),
+        randomized SVD with 20 oversamples and 2 power iterations, rank 50 (--rank 200).
+  small: 65536 x 1024, smoke only.
+The default for --workload can also be set with DMDX_BENCH_WORKLOAD (the driver passes no flags).
+A step = one full SVD with X resident in HBM.
 
 Output: ONE JSON line on rank 0 (contract in the task statement) with
-  value        = N * m * n * 4 bytes * K / wall      [GB/s]
-  roofline     = fp32-MFMA roofline of the Gram kernel: algorithmic flops m*n*(n+1)
-                 per launch / average launch time measured with HIP events on the
-                 launch stream inside the timed region; peak 157.3 TFLOP/s
-  cpu_baseline = the oracle's `svd_standard` (np.linalg.svd + slice == the reference's
-                 call, era5_svd.py:251) timed on a bounded sample of the same X on
-                 the host cores (N = 1 only).
+  value          = rows of all ranks * n * 4 bytes * K / max-over-ranks wall      [GB/s]
+  roofline       = fp32-MFMA roofline of the Gram kernel (standard workloads): algorithmic flops
+                   m*n*(n+1) per launch / average launch time measured with HIP events on the
+                   launch stream inside the timed region; peak 157.3 TFLOP/s
+  hard_spectrum  = (N = 1, cfg2) the same step on the gap-free power-law matrix
+                   (make_powerlaw_blocks), outside the timed region: ms per step and the share
+                   of the eigen stage, which no longer depends on the spectrum
+  cpu_baseline   = (N = 1) the reference's two CPU calls, np.linalg.svd(...)[:r]
+                   (era5_svd.py:251) and sklearn randomized_svd(X, r) (era5_svd.py:258), timed
+                   on a bounded sample (8760 leading rows x every 2nd column: ~26 s; all columns
+                   with --cpu-baseline-full: ~200 s) of the same X on the host cores, plus the HIP
+                   engine's singular values of that same sample against the CPU's (parity gate)
+  world_size / devices / backend = what the ranks actually saw.
 """
 from __future__ import annotations
 
@@ -40,12 +53,20 @@ sys.path.insert(0, ROOT)
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: 256 CU x 256 flop/clk x 2.4 GHz
 
 WORKLOADS = {
-    # name: (m, n, rank, description)
+    # name: (m, n, rank, description)   -- m = rows per GPU (weak) or in total (strong)
     "cfg2": (721 * 1440, 8760, 50,
              "cfg2: 1038240x8760 fp32 synthetic low-rank(64)+noise, row-centred, rank-50 "
              "method-of-snapshots SVD"),
+    "cfg3": (15 * 721 * 1440 // 8, 8760, 200,
+             "cfg3: 1946700 rows per GPU x 8760 fp32 (15573600 x 8760 at N = 8), rank-200 "
+             "method-of-snapshots SVD, row-sharded, one Gram all-reduce per step"),
+    "cfg4": (15 * 721 * 1440, 3653, 50,
+             "cfg4: 15573600x3653 fp32 in total (rows / N per GPU), randomized SVD, 20 oversamples, "
+             "2 power iterations"),
     "small": (65536, 1024, 50, "small: 65536x1024 fp32 synthetic, rank-50 (smoke only)"),
 }
+WORKLOAD_KIND = {"cfg2": ("standard", "weak"), "cfg3": ("standard", "weak"), "cfg4": ("randomized", "strong"),
+                 "small": ("standard", "weak")}
 
 
 def make_snapshot_blocks(m: int, n: int, seed: int, device, shard: int = 0) -> list[torch.Tensor]:
@@ -84,7 +105,7 @@ def make_snapshot_blocks(m: int, n: int, seed: int, device, shard: int = 0) -> l
 def make_powerlaw_blocks(m: int, n: int, seed: int, device, shard: int = 0) -> list[torch.Tensor]:
     """The gap-free counterpart of :func:`make_snapshot_blocks` (ERA5 anomalies have power-law
     spectra, not a gap behind the wanted rank): X = X0 W with X0 (m x n) Gaussian noise and
-    W = B diag(sigma) H^T / sqrt(m_total-ish), B and H random orthogonal (n x n), sigma_i = 100 / i
+    W = B diag(sigma) H^T, B and H random orthogonal (n x n), sigma_i = 100 / i
     over ALL n columns.  X0^T X0 / m = I + O(sqrt(n/m)), so the singular values of X are
     sigma_i sqrt(m) within the Marchenko-Pastur edge factors 1 +- sqrt(n/m) and every consecutive
     ratio is (i+1)/i: no gap anywhere.  Row blocks as (n, mb) fp32 tensors; the time factor W is
@@ -107,10 +128,13 @@ def make_powerlaw_blocks(m: int, n: int, seed: int, device, shard: int = 0) -> l
     return blocks
 
 
-def calibrate(device) -> dict:
+def calibrate(device, kern=None, blocks=None) -> dict:
     """What this GPU sustains, next to the nominal peaks the roofline is priced against
-    (SURVEY.md 8d): a register-only fp32 MFMA loop (dmdx_calib_mfma_f32, 2 waves per SIMD) and a
-    4 GiB device-to-device copy.  Reported only; `roofline.peak` stays the nominal 157.3."""
+    (SURVEY.md 8d): a register-only fp32 MFMA loop (dmdx_calib_mfma_f32, 2 waves per SIMD), a
+    4 GiB device-to-device copy, and -- so that a slow box can be attributed to its clock -- the
+    core clock the chip holds while the Gram kernel itself runs: one extra launch of K1 over
+    `blocks` with per-workgroup s_memtime / s_memrealtime stamps (dmdx_set_clock_probe).
+    Reported only; `roofline.peak` stays the nominal 157.3 at 2.4 GHz."""
     import ctypes as C
 
     from dmd_era5_amd import _lib
@@ -141,22 +165,59 @@ def calibrate(device) -> dict:
         if it:
             copy = max(copy, 2.0 * a.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e12)
     del a, b
-    return {"mfma_f32_tflops_measured": best, "mfma_f32_tflops_nominal": PEAK_FP32_MFMA_TFLOPS,
-            "hbm_copy_TBps_measured": copy, "hbm_TBps_nominal": 8.0, "compute_units": cus,
-            "how": "dmdx_calib_mfma_f32: 16 x 200000 v_mfma_f32_32x32x2_f32 per wave, 8 waves per CU; "
-                   "torch copy of 4 GiB (read + write bytes)"}
+    out = {"mfma_f32_tflops_measured": best, "mfma_f32_tflops_nominal": PEAK_FP32_MFMA_TFLOPS,
+           "hbm_copy_TBps_measured": copy, "hbm_TBps_nominal": 8.0, "compute_units": cus,
+           "how": "dmdx_calib_mfma_f32: 16 x 200000 v_mfma_f32_32x32x2_f32 per wave, 8 waves per CU; "
+                  "torch copy of 4 GiB (read + write bytes)"}
+    if kern is not None and blocks is not None and len(blocks) > 1:
+        ctr = torch.zeros(3, dtype=torch.int64, device=device)
+        kern.clock_probe(ctr)
+        try:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            kern.syrk_blocks(blocks)
+            e1.record()
+            e1.synchronize()
+        finally:
+            kern.clock_probe(None)
+        cyc, ticks, wgs = (int(v) for v in ctr.tolist())
+        if ticks > 0:
+            out["k1_core_clock_mhz"] = 100.0 * cyc / ticks
+            out["k1_core_clock_how"] = (f"sum of s_memtime cycles / sum of 100 MHz s_memrealtime ticks over the {wgs} "
+                                        f"workgroups of one probed Gram launch ({e0.elapsed_time(e1):.1f} ms with the "
+                                        "reduce kernel); the roofline peak assumes 2400 MHz")
+            out["k1_peak_at_held_clock_tflops"] = PEAK_FP32_MFMA_TFLOPS * out["k1_core_clock_mhz"] / 2400.0
+    return out
 
 
-def cpu_baseline(Xt: torch.Tensor, r: int) -> dict:
-    """Oracle (np.linalg.svd + slice) on a bounded sample (leading rows of the first
-    row block) of the same matrix."""
+def cpu_baseline(Xt: torch.Tensor, r: int, kern, rows: int | None = None, m_full: int | None = None,
+                 full_width: bool = False) -> dict:
+    """The reference's two CPU calls on a bounded sample of the same X, and the HIP engine on that
+    very sample (parity gate).
+
+    Sample: the leading `rows` space points of the first row block x every 2nd column (n_s = 4380
+    of cfg2's 8760; `--cpu-baseline-full`: all n columns), rows = 2 n_s by default, copied to the
+    host as the F-ordered (rows, n_s) fp32 array the reference hands to LAPACK (svd_on_era5,
+    era5_svd.py:246).  Timed: oracle.svd_standard = np.linalg.svd(X, full_matrices=False) + slice
+    (era5_svd.py:251-254) and sklearn's randomized_svd(X, r) with the reference's defaults
+    (era5_svd.py:258).  gesdd costs ~6 rows n^2 + 20 n^3 flops: the full-width sample (17520 x
+    8760) takes 204 s on the box's 128 host threads (profiles/r2_bench_cpu_full.json), the
+    smallest tall full-width one (rows = n) still ~165 s, so the default run -- which has to end
+    within minutes -- halves the width (~1/8 of the work per row: ~26 s) and says so;
+    `extrapolated_full_seconds` scales the measured time by (m / rows) (n / n_s)^2, linear in the
+    rows and quadratic in the columns: the m n^2 term of gesdd, a LOWER bound of what the
+    reference's call on the whole 1 038 240 x 8760 matrix costs (and it needs > 3 |X| = 110 GB
+    of host RAM there)."""
+    import resource
+
     from oracle import era5_oracle as orc
 
-    n, m = Xt.shape
-    cs = 4 if n >= 4096 else 1
-    ms = min(m, 32445 if n >= 4096 else 8192)
-    sample = Xt[::cs, :ms].contiguous().cpu().numpy()          # (n_s, m_s) C-order
-    Xs = sample.T                                              # (m_s, n_s) F-order, as the reference's X
+    n_all, m = Xt.shape
+    cs = 1 if (full_width or n_all < 4096) else 2
+    n = len(range(0, n_all, cs))
+    ms = min(m, rows or 2 * n)
+    sample_dev = Xt[::cs, :ms].contiguous()
+    Xs = sample_dev.cpu().numpy().T                                # (ms, n) F-order view, as the reference's X
     try:
         from threadpoolctl import threadpool_info
 
@@ -166,18 +227,77 @@ def cpu_baseline(Xt: torch.Tensor, r: int) -> dict:
     t0 = time.perf_counter()
     U, s, V = orc.svd_standard(Xs, r)
     dt = time.perf_counter() - t0
-    return {
+    out = {
         "value": Xs.nbytes / dt / 1e9,
         "unit": "GB/s",
         "cores": int(cores),
         "kind": "port",
         "seconds": dt,
-        "sample": f"oracle.svd_standard (np.linalg.svd + slice, the reference's era5_svd.py:251 "
-                  f"call) on rows[0:{ms}] x every {cs}th column = {Xs.shape[0]}x{Xs.shape[1]} fp32 "
-                  f"F-order of the same X; LAPACK cost per byte grows ~linearly with n, so the "
-                  f"full-width rate is ~{cs}x lower",
+        "sample": f"oracle.svd_standard (np.linalg.svd(X, full_matrices=False)[:r], the reference's "
+                  f"era5_svd.py:251 call) on rows[0:{ms}] x {'all' if cs == 1 else f'every {cs}nd of the'} {n_all} columns "
+                  f"= {ms}x{n} fp32 F-order of the same X ({Xs.nbytes / 1e9:.2f} GB)",
+        "extrapolated_full_seconds": dt * ((m_full or m) / ms) * (n_all / n) ** 2,
+        "extrapolation": f"measured seconds x ({m_full or m} / {ms} rows) x ({n_all} / {n} columns)^2: the m n^2 term "
+                         "of gesdd only, a lower bound for the whole matrix",
         "s_head": [float(x) for x in s[:3]],
     }
+    try:
+        from sklearn.utils.extmath import randomized_svd
+
+        t0 = time.perf_counter()
+        _, s_r, _ = randomized_svd(Xs, r, random_state=0)
+        dtr = time.perf_counter() - t0
+        out["randomized"] = {"value": Xs.nbytes / dtr / 1e9, "unit": "GB/s", "seconds": dtr,
+                             "call": "sklearn.utils.extmath.randomized_svd(X, r) with the reference's defaults "
+                                     "(era5_svd.py:258; random_state=0 here)",
+                             "max_rel_diff_s_vs_standard": float(np.max(np.abs(s_r - s) / s))}
+    except Exception as e:  # sklearn missing on the box: say so, do not fail the bench
+        out["randomized"] = {"error": repr(e)}
+    out["peak_rss_gb"] = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1e6
+    # parity gate: the HIP engine on the very same sample
+    from dmd_era5_amd import svd as dsvd
+
+    res = dsvd.svd_snapshots(sample_dev, r, kern=kern)
+    s_gpu = res.s.cpu().numpy()
+    out["parity"] = {"max_rel_err_s": float(np.max(np.abs(s_gpu - s.astype(np.float64)) / s.astype(np.float64))),
+                     "min_abs_cos_u": float(np.min(np.abs(np.sum(res.Ut.cpu().numpy().T.astype(np.float64)
+                                                                 * U.astype(np.float64), axis=0)))),
+                     "what": f"svd_snapshots (HIP) vs np.linalg.svd (fp32 LAPACK) on the same {ms}x{n} sample, "
+                             f"{r} singular values / left vectors"}
+    return out
+
+
+def hard_spectrum(m: int, n: int, r: int, device, kern, steps: int = 2) -> dict:
+    """The standard path on the gap-free power-law matrix of the same size (N = 1 only, outside
+    the timed region): ms per step and the stage split.  ERA5 anomalies look like this, not like
+    the planted rank-64 + noise matrix whose eigenproblem three power steps finish."""
+    from dmd_era5_amd import svd as dsvd
+
+    blocks = make_powerlaw_blocks(m, n, 1234, device)
+    for Xb in blocks:
+        kern.row_center_scale_(Xb, False)
+    dsvd.svd_snapshots(blocks, r, kern=kern)
+    torch.cuda.synchronize()
+    acc: dict[str, float] = {}
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        res = dsvd.svd_snapshots(blocks, r, kern=kern, timings=True)
+        for k in ("t_gram", "t_eig", "t_project", "t_refine", "t_total"):
+            acc[k] = acc.get(k, 0.0) + res.info[k]
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    out = {"spectrum": "sigma_i = 100 / i over all n columns (make_powerlaw_blocks)", "steps": steps,
+           "ms_per_step": dt * 1e3, "value_GBps": m * n * 4.0 / dt / 1e9,
+           "gram_ms": acc["t_gram"] / steps * 1e3, "eig_ms": acc["t_eig"] / steps * 1e3,
+           "project_ms": acc["t_project"] / steps * 1e3, "refine_ms": acc["t_refine"] / steps * 1e3,
+           "eig_share": acc["t_eig"] / acc["t_total"],
+           "eig_method": res.info.get("eig_method"), "eig_products": res.info.get("eig_products"),
+           "eig_degrees": res.info.get("eig_degrees"), "eig_block": res.info.get("eig_block"),
+           "sweeps": res.info.get("eig_outer_iters"),
+           "s_head": [float(x) for x in res.s[:3].cpu()]}
+    del blocks
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -185,10 +305,18 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=os.environ.get("DMDX_BENCH_WORKLOAD", "cfg2"), choices=sorted(WORKLOADS))
+    ap.add_argument("--rank", type=int, default=None, help="override the workload's rank (cfg4: 50 or 200)")
+    ap.add_argument("--spectrum", default="planted", choices=["planted", "powerlaw"],
+                    help="powerlaw: run the timed steps themselves on the gap-free matrix")
+    ap.add_argument("--no-hard-spectrum", action="store_true",
+                    help="skip the extra power-law steps reported under `hard_spectrum` (N = 1, cfg2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-rows", type=int, default=None, help="rows of the CPU sample (default 2 n_s)")
+    ap.add_argument("--cpu-baseline-full", action="store_true",
+                    help="CPU sample over ALL n columns (17520 x 8760 at cfg2: ~200 s of np.linalg.svd)")
     ap.add_argument("--no-calibrate", action="store_true",
-                    help="skip the ~0.3 s on-box micro-benchmarks (register-only fp32 MFMA loop, HBM copy)")
+                    help="skip the ~0.3 s on-box micro-benchmarks (register-only fp32 MFMA loop, HBM copy, K1 clock)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -208,6 +336,8 @@ def main():
     from dmd_era5_amd.kernels import default_kernels
 
     kern = default_kernels()  # fails loudly if libdmdx.so is missing
+    backend = None
+    devices = [{"rank": 0, "device_index": dev_index, "name": torch.cuda.get_device_name(device)}]
     if world > 1:
         import torch.distributed as dist
 
@@ -221,18 +351,37 @@ def main():
         # bring the RCCL communicator up outside the timed region whatever --warmup is
         dist.all_reduce(torch.zeros(1, device=device))
         torch.cuda.synchronize()
+        mine = {"rank": rank, "device_index": dev_index, "name": torch.cuda.get_device_name(device),
+                "pci_bus_id": getattr(torch.cuda.get_device_properties(device), "pci_bus_id", None)}
+        devices = [None] * world
+        dist.all_gather_object(devices, mine)
+        backend = f"{dist.get_backend()} (torch.distributed; on ROCm 'nccl' is RCCL)"
     else:
         dist = None
         comm = dsvd.Comm()
 
     m, n, r, desc = WORKLOADS[args.workload]
-    blocks = make_snapshot_blocks(m, n, 1234, device, shard=rank)
+    svd_type, scaling = WORKLOAD_KIND[args.workload]
+    svd_type = os.environ.get("DMDX_BENCH_SVD_TYPE", svd_type)     # rehearsal knob (tests)
+    if args.rank:
+        r = args.rank
+    if scaling == "strong":                       # rows of ONE matrix split over the ranks
+        cuts = [m * i // world for i in range(world + 1)]
+        m_total, m = m, cuts[rank + 1] - cuts[rank]
+    else:
+        m_total = m * world
+    gen = make_powerlaw_blocks if args.spectrum == "powerlaw" else make_snapshot_blocks
+    blocks = gen(m, n, 1234 if args.workload != "cfg4" else 99, device, shard=rank)
     for Xb in blocks:
         kern.row_center_scale_(Xb, False)
     torch.cuda.synchronize()
 
-    def step():
-        return dsvd.svd_snapshots(blocks, r, comm=comm, kern=kern)
+    if svd_type == "standard":
+        def step():
+            return dsvd.svd_snapshots(blocks, r, comm=comm, kern=kern)
+    else:
+        def step():
+            return dsvd.svd_randomized(blocks, r, n_oversamples=20, n_iter=2, random_state=0, comm=comm, kern=kern)
 
     # library handles / code objects (rocBLAS, rocSOLVER, libdmdx) are created on first use: prime
     # them on a toy problem so that --warmup 0 does not time their initialisation
@@ -250,21 +399,21 @@ def main():
     for _ in range(args.warmup):
         res = step()
     barrier()
-    kern.events = []
+    # per-launch HIP events: ~20 launches per standard step (free); the randomized path issues
+    # thousands of launches per step, where recording them would be the thing measured
+    kern.events = [] if svd_type == "standard" else None
     t0 = time.perf_counter()
     for _ in range(args.steps):
         res = step()
     barrier()
     dt = time.perf_counter() - t0
-    events, kern.events = kern.events, None
+    events, kern.events = (kern.events or []), None
     if dist is not None:
         tmax = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
     # per-kernel times from the HIP events recorded inside the timed region
-    # (the Gram is one launch per row block: per-launch figures are sums over the blocks
-    # of one step divided by the launches; flops likewise)
     # (the Gram of the row blocks is ONE launch of the batched K1, dmdx_syrk_blocks_f32,
     # followed by its reduce kernel on the same stream; both are inside the event pair)
     by_name: dict[str, list[float]] = {}
@@ -274,42 +423,49 @@ def main():
             key = "syrk" if shape[1] == n else "syrk_small"
         by_name.setdefault(key, []).append(e0.elapsed_time(e1))
     nblk = len(blocks)
-    syrk_ms = float(np.mean(by_name["syrk"]))            # average Gram launch (all row blocks of X)
-    flops = float(m) * n * (n + 1)                         # algorithmic flops of that launch
-    achieved = flops / (syrk_ms * 1e-3) / 1e12
-
-    # HBM-side traffic of the Gram kernel: PMC numbers cannot be collected from inside this
-    # process; they come from the committed rocprofv3 --pmc passes of this same command
-    # (profiles/r1_bench_rocprof_summary.json: FETCH_SIZE doubled per the gfx950 note of
-    # MI355X_MICROARCH.md, plus WRITE_SIZE, per launch).
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r1_bench_rocprof_summary.json")) as f:
-            prof = json.load(f)
-        if args.workload == "cfg2":
-            traffic = float(prof["traffic"]["bytes_per_launch_corrected"])
-    except Exception:
-        traffic = None
 
     out = {
         "metric": "rank-r SVD GB/s on ERA5 snapshot matrix (X resident in HBM)",
-        "value": world * m * n * 4.0 * args.steps / dt / 1e9,
+        "value": m_total * n * 4.0 * args.steps / dt / 1e9,
         "unit": "GB/s",
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": scaling,
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": desc,
-            "m_per_gpu": m, "n": n, "rank": r, "svd_type": "standard",
-            "sharding": f"rows x{world}, one Gram all-reduce per step" if world > 1 else "none",
+            "workload": desc + (" [power-law spectrum]" if args.spectrum == "powerlaw" else ""),
+            "m_per_gpu": m, "m_total": m_total, "n": n, "rank": r, "svd_type": svd_type,
+            "sharding": (f"rows x{world}, one packed-triangle Gram all-reduce per step" if svd_type == "standard"
+                         else f"rows x{world}, n x l and l x l all-reduces per pass") if world > 1 else "none",
         },
-        "roofline": {
+        "world_size": world,
+        "backend": backend,
+        "devices": devices,
+    }
+    if svd_type == "standard":
+        syrk_ms = float(np.mean(by_name["syrk"]))            # average Gram launch (all row blocks of X)
+        flops = float(m) * n * (n + 1)                         # algorithmic flops of that launch
+        achieved = flops / (syrk_ms * 1e-3) / 1e12
+        # HBM-side traffic of the Gram kernel: PMC numbers cannot be collected from inside this
+        # process; they come from the committed rocprofv3 --pmc passes of this same command
+        # (profiles/r2_bench_rocprof_summary.json, else round 1's: FETCH_SIZE doubled per the gfx950
+        # note of MI355X_MICROARCH.md, plus WRITE_SIZE, per launch).
+        traffic, traffic_src = None, None
+        if args.workload == "cfg2" and args.spectrum == "planted":
+            for name in ("r2_bench_rocprof_summary.json", "r1_bench_rocprof_summary.json"):
+                try:
+                    with open(os.path.join(ROOT, "profiles", name)) as f:
+                        traffic = float(json.load(f)["traffic"]["bytes_per_launch_corrected"])
+                    traffic_src = name
+                    break
+                except Exception:
+                    continue
+        out["roofline"] = {
             "bound": "mfma",
             "kernel": "syrk_batch_kernel (K1 Gram of all row blocks in one launch, dmdx_syrk_blocks_f32)",
             "achieved": achieved,
@@ -317,20 +473,34 @@ def main():
             "unit": "TFLOP/s",
             "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
             "traffic": traffic,
-            "traffic_unit": "bytes/launch (L2<->fabric, PMC; profiles/r1_bench_rocprof_summary.json)",
+            "traffic_unit": f"bytes/launch (L2<->fabric, PMC; profiles/{traffic_src})" if traffic_src else None,
             "flops_per_launch": flops,
             "ms_per_launch": syrk_ms,
-        },
-        "kernel_ms_per_step": {k: float(np.sum(v)) / args.steps for k, v in by_name.items()},
-        "row_blocks": nblk,
-        "svd_info": {k: (float(v) if isinstance(v, (int, float)) else v)
-                     for k, v in (res.info if res is not None else {}).items()},
-        "s_head": [float(x) for x in res.s[:3].cpu()] if res is not None else None,
-    }
+        }
+    else:
+        # randomized: 2 n_iter + 2 = 6 passes over X of 2 m n l flops each (K2 / K3 alternate); the
+        # per-kernel split lives in profiles/ (rocprofv3 --kernel-trace of scripts/bench_cfg4.py)
+        l = r + 20
+        flops = 6 * 2.0 * m * n * l
+        out["roofline"] = {"bound": "mfma", "kernel": "K2 skinny + K3 gemm_tn, 6 passes over X",
+                           "achieved": flops * args.steps / dt / 1e12, "peak": PEAK_FP32_MFMA_TFLOPS,
+                           "unit": "TFLOP/s", "frac": flops * args.steps / dt / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                           "traffic": None, "flops_per_step": flops,
+                           "note": "whole-step algorithmic rate (no per-launch events in the timed region)"}
+    out["kernel_ms_per_step"] = {k: float(np.sum(v)) / args.steps for k, v in by_name.items()}
+    out["row_blocks"] = nblk
+    out["svd_info"] = {k: (float(v) if isinstance(v, (int, float)) else v)
+                       for k, v in (res.info if res is not None else {}).items()}
+    out["s_head"] = [float(x) for x in res.s[:3].cpu()] if res is not None else None
     if rank == 0 and world == 1 and not args.no_calibrate:
-        out["calibration"] = calibrate(device)
+        out["calibration"] = calibrate(device, kern, blocks if svd_type == "standard" else None)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(blocks[0], r)
+        out["cpu_baseline"] = cpu_baseline(blocks[0], r, kern, args.cpu_baseline_rows, m, args.cpu_baseline_full)
+    if rank == 0 and world == 1 and not args.no_hard_spectrum and args.workload == "cfg2" and args.spectrum == "planted":
+        del blocks
+        kern.release_workspace()
+        torch.cuda.empty_cache()
+        out["hard_spectrum"] = hard_spectrum(m, n, r, device, kern)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -390,3 +390,46 @@ def test_main_streams_a_slice_that_does_not_fit(svd_base_config, tmp_path, monke
         assert np.array_equal(b["X_mean"].values, a["X_mean"].values)
         if scale:
             assert np.allclose(b["X_std"].values, a["X_std"].values, rtol=1e-6)
+
+
+@pytest.mark.parametrize("workload", ["small", "small-randomized"])
+def test_bench_two_ranks_on_one_gpu_over_gloo(workload):
+    """bench.py's N > 1 path as the driver launches it (torch.distributed.run, one process per
+    rank, RANK / LOCAL_RANK / WORLD_SIZE from the environment) -- rehearsed with two ranks on the
+    box's one GPU over gloo (DMDX_BENCH_DEVICE / DMDX_DIST_BACKEND; RCCL needs one GPU per rank and
+    is the driver's 8-GPU run).  The line must say what the ranks saw: world size, backend, one
+    device entry per rank; row shards of ONE global matrix: the singular values of the 2-rank run
+    are those of the stacked matrix (sqrt(2) x the planted single-shard ones, 5 %)."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, DMDX_BENCH_DEVICE="0", DMDX_DIST_BACKEND="gloo")
+    extra = ["--workload", "small"]
+    if workload == "small-randomized":
+        env["DMDX_BENCH_SVD_TYPE"] = "randomized"
+    run = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port),
+                          os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"] + extra,
+                         env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert run.returncode == 0, run.stdout[-3000:] + run.stderr[-3000:]
+    lines = [ln for ln in run.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, run.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["world_size"] == 2 and out["steps"] == 2 and out["scaling"] == "weak"
+    assert out["backend"].startswith("gloo") and [d["rank"] for d in out["devices"]] == [0, 1]
+    assert all(d["device_index"] == 0 for d in out["devices"])
+    assert out["value"] > 0 and out["unit"] == "GB/s" and out["config"]["m_total"] == 2 * out["config"]["m_per_gpu"]
+    assert "cpu_baseline" not in out and "hard_spectrum" not in out          # N = 1 only
+    m, n = out["config"]["m_total"], out["config"]["n"]
+    planted = 100.0 * 0.9 ** np.arange(3) * np.sqrt(float(m) * n)
+    assert np.all(np.abs(np.array(out["s_head"]) / planted - 1.0) < 0.05), out["s_head"]
+    if workload == "small":
+        assert out["roofline"]["bound"] == "mfma" and out["roofline"]["frac"] > 0
+        assert "one packed-triangle Gram all-reduce" in out["config"]["sharding"]

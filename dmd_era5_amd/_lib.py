@@ -43,6 +43,9 @@ SIGNATURES = {
     "dmdx_scale_columns_f32": (C.c_int, [_p, _i64, _i64, _i64, _p, _p]),
     "dmdx_eigh_small_max_n": (C.c_int, []),
     "dmdx_eigh_small_f64": (C.c_int, [_p, _i64, _i64, _p, _p, _i64, _p, _p]),
+    "dmdx_svd_jacobi_max_n": (C.c_int, []),
+    "dmdx_svd_jacobi_workspace_bytes": (_sz, [_i64]),
+    "dmdx_svd_jacobi_f64": (C.c_int, [_p, _i64, _i64, _p, _p, _i64, _p, _p, _sz, _p]),
     "dmdx_symm_skinny_workspace_bytes": (_sz, [_i64, _i64]),
     "dmdx_symm_skinny_f64": (C.c_int, [_p, _i64, _i64, _p, _i64, _i64, C.c_double, _p, _i64, _p, _sz, _p]),
     "dmdx_pack_triu_f64": (C.c_int, [_p, _i64, _i64, _p, _p]),

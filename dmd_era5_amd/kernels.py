@@ -292,12 +292,49 @@ class HipKernels:
         n = T.shape[0]
         w = torch.empty(n, dtype=torch.float64, device=T.device)
         V = torch.empty((n, n), dtype=torch.float64, device=T.device)
+        info = torch.zeros(1, dtype=torch.int32, device=T.device)
         rc = self._timed("eigh_small", (n,), lambda: self._lib.dmdx_eigh_small_f64(
-            _ptr(T), n, T.stride(0), _ptr(w), _ptr(V), n, None, self._stream()
+            _ptr(T), n, T.stride(0), _ptr(w), _ptr(V), n, _ptr(info), self._stream()
         ))
         _lib.check(rc, "dmdx_eigh_small_f64")
+        # the kernel stops silently at its sweep limit (30): eigenpairs of a run that did not
+        # converge must not be used as exact by the Rayleigh-Ritz steps
+        self.last_eigh_sweeps = int(info.item())
+        if self.last_eigh_sweeps >= 30:
+            raise _lib.DmdxError(f"eigh_small: no convergence in {self.last_eigh_sweeps} Jacobi sweeps (n = {n})")
         return w, V
 
+
+    # -- K7L ----------------------------------------------------------------
+    @property
+    def svd_jacobi_max_n(self) -> int:
+        return int(self._lib.dmdx_svd_jacobi_max_n())
+
+    def svd_jacobi(self, Ct: torch.Tensor):
+        """One-sided Jacobi SVD of a square fp64 device matrix C, given as ``Ct`` with row c =
+        column c of C (2 <= n <= svd_jacobi_max_n), one launch: -> (sigma (n,) descending,
+        Zt (n, n) with row j = left singular vector j).  ``Ct`` is overwritten.  Raises if the
+        workgroups of the launch could not synchronise or the sweeps did not converge."""
+        if Ct.dim() != 2 or Ct.shape[0] != Ct.shape[1] or Ct.dtype != torch.float64 or not Ct.is_cuda \
+                or Ct.stride(1) != 1:
+            raise _lib.DmdxError("svd_jacobi: Ct must be a square fp64 device matrix with inner stride 1")
+        n = Ct.shape[0]
+        sigma = torch.empty(n, dtype=torch.float64, device=Ct.device)
+        Zt = torch.empty((n, n), dtype=torch.float64, device=Ct.device)
+        info = torch.zeros(1, dtype=torch.int32, device=Ct.device)
+        ws = torch.empty(self._lib.dmdx_svd_jacobi_workspace_bytes(n), dtype=torch.uint8, device=Ct.device)
+        rc = self._timed("svd_jacobi", (n,), lambda: self._lib.dmdx_svd_jacobi_f64(
+            _ptr(Ct), n, Ct.stride(0), _ptr(sigma), _ptr(Zt), n, _ptr(info), _ptr(ws), ws.numel(), self._stream()
+        ))
+        _lib.check(rc, "dmdx_svd_jacobi_f64")
+        sweeps = int(info.item())
+        if sweeps < 0:
+            raise _lib.DmdxError("svd_jacobi: the workgroups of the launch could not synchronise "
+                                 "(the device is occupied by another kernel that does not end)")
+        if sweeps >= 40:
+            raise _lib.DmdxError(f"svd_jacobi: no convergence in {sweeps} sweeps (n = {n})")
+        self.last_jacobi_sweeps = sweeps
+        return sigma, Zt
 
     # -- K8 -----------------------------------------------------------------
     def symm_skinny(self, G: torch.Tensor, Q: torch.Tensor, shift: float = 0.0,

@@ -200,13 +200,40 @@ def _orth(Y: torch.Tensor, rounds: int = 2) -> torch.Tensor:
     return Q.contiguous()
 
 
+def _jacobi_pd_eigh(C_t: torch.Tensor, kern):
+    """Eigenpairs (descending) of T = C C^T from the one-sided Jacobi SVD of C (K7L), C given
+    column by column (row c of ``C_t`` = column c of C): (sigma^2, Z)."""
+    sig, Zt = kern.svd_jacobi(C_t)
+    return sig * sig, Zt.T
+
+
 def _eigh_desc(T: torch.Tensor, kern=None):
     """Eigenpairs of a small symmetric fp64 matrix, eigenvalues descending, eigenvectors in
-    columns.  Up to the provider's ``eigh_small_max_n`` (96) this is ONE launch of the Jacobi
-    kernel K7; rocSOLVER's syevd (torch.linalg.eigh) is launch-rate bound at these sizes."""
+    columns.  Up to the provider's ``eigh_small_max_n`` (96) this is ONE launch of the two-sided
+    Jacobi kernel K7; up to ``svd_jacobi_max_n`` (1024) one launch of the one-sided Jacobi kernel
+    K7L on the Cholesky factor of T (the Rayleigh-Ritz matrices of a PSD Gram matrix are positive
+    definite up to its rounding; if the factorisation fails T is shifted by 1e-8 of its mean
+    diagonal first -- the vectors do not change, the values are shifted back, which costs them
+    nothing at the absolute accuracy a Rayleigh-Ritz step needs).  rocSOLVER's syevd
+    (torch.linalg.eigh) is launch-rate bound at these sizes and remains the fallback."""
     n = T.shape[0]
     if kern is not None and n <= getattr(kern, "eigh_small_max_n", 0):
-        return kern.eigh_small(T)
+        try:
+            return kern.eigh_small(T)
+        except RuntimeError:
+            pass
+    elif kern is not None and n <= getattr(kern, "svd_jacobi_max_n", 0):
+        shift = 0.0
+        L, err = torch.linalg.cholesky_ex(T)
+        if int(err) != 0 or not bool(torch.isfinite(torch.diagonal(L)).all()):
+            shift = 1e-8 * float(torch.diagonal(T).abs().mean())
+            L, err = torch.linalg.cholesky_ex(T + shift * torch.eye(n, dtype=T.dtype, device=T.device))
+        if int(err) == 0 and bool(torch.isfinite(torch.diagonal(L)).all()):
+            try:
+                lam, Z = _jacobi_pd_eigh(L.T.contiguous(), kern)
+                return lam - shift, Z
+            except RuntimeError:
+                pass
     th, Z = torch.linalg.eigh(T)
     return torch.flip(th, dims=(0,)), torch.flip(Z, dims=(1,))
 
@@ -232,11 +259,22 @@ def _graded_eigh(s0: torch.Tensor, Mm: torch.Tensor, kern=None):
     L, err = torch.linalg.cholesky_ex(0.5 * (Mg + Mg.T))
     if int(err.item()) != 0 or not bool(torch.isfinite(L).all()):
         return _eigh_desc(T, kern)
-    _, sig, Vbh = torch.linalg.svd(L.T * s0[g][None, :])
+    Zg = None
+    if kern is not None and 2 <= lg <= getattr(kern, "svd_jacobi_max_n", 0):
+        # K7L on C = S L (column c of C = s * L[:, c]): T_g = C C^T, eigenvectors = left singular
+        # vectors, errors relative to each singular value; one launch instead of gesvd's ~40 ms
+        try:
+            sig, Zt = kern.svd_jacobi((L.T * s0[g][None, :]).contiguous())
+            Zg = Zt.T
+        except RuntimeError:
+            Zg = None
+    if Zg is None:
+        _, sig, Vbh = torch.linalg.svd(L.T * s0[g][None, :])
+        Zg = Vbh.T
     mu = torch.zeros(l, dtype=T.dtype, device=T.device)
     mu[:lg] = sig * sig
     Z = torch.zeros((l, l), dtype=T.dtype, device=T.device)
-    Z[g, :lg] = Vbh.T
+    Z[g, :lg] = Zg
     if lg < l:   # directions dropped from S: eigenvalue 0, unit eigenvectors
         rest = torch.nonzero(s0 <= 0).squeeze(1)
         Z[rest, torch.arange(lg, l, device=T.device)] = 1.0

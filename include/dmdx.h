@@ -134,6 +134,22 @@ int dmdx_eigh_small_max_n(void);
 int dmdx_eigh_small_f64(const double* A, int64_t n, int64_t lda, double* w, double* V,
                         int64_t ldv, int* sweeps, void* stream);
 
+/* ---- K7L: one-sided Jacobi SVD of a square fp64 matrix, 2 <= n <= dmdx_svd_jacobi_max_n() (1024),
+ * one launch of <= 64 workgroups (they synchronise through a counter in the workspace: the launch
+ * must be able to run them all at once, i.e. nothing else may occupy the device for good).
+ * C: n x n, COLUMN c at C + c * ldc (contiguous), overwritten.  sigma[0..n): singular values in
+ * DESCENDING order; Zt (n x n, ldz): ROW j = unit left singular vector of sigma[j] (zero rows for
+ * zero singular values).  sweeps (nullable device int): sweeps used, -1 if the workgroups could
+ * not synchronise (results invalid).  With C = chol(T) (or S L for T = S L L^T S) this gives
+ * the eigenpairs of the positive definite T = C C^T with errors relative to each eigenvalue:
+ * the (b x b) Rayleigh-Ritz matrices and the graded refinement matrix of the method of
+ * snapshots beyond K7's n <= 96 -- the LAPACK syevd / gesvd calls left of np.linalg.svd
+ * (era5_svd.py:251) once X is reduced to its Gram matrix. */
+int dmdx_svd_jacobi_max_n(void);
+size_t dmdx_svd_jacobi_workspace_bytes(int64_t n);
+int dmdx_svd_jacobi_f64(double* C, int64_t n, int64_t ldc, double* sigma, double* Zt, int64_t ldz,
+                        int* sweeps, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- K8: Y = G Q - shift Q, G symmetric n x n fp64, Q / Y n x b row-major (ldq, ldy) ------
  * The products of the top-eigenpair solver on the Gram matrix (the part of np.linalg.svd,
  * era5_svd.py:251, left once X is reduced to G): fp64 MFMA, G streamed once, Q staged in LDS,

@@ -83,6 +83,12 @@ class CpuKernelDouble:
         A[j, i] = packed
         return A
 
+    svd_jacobi_max_n = 1024
+
+    def svd_jacobi(self, Ct):
+        U, s, _ = torch.linalg.svd(Ct.T)
+        return s, U.T.contiguous()
+
     eigh_small_max_n = 96
 
     def eigh_small(self, T):

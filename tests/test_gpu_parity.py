@@ -524,6 +524,81 @@ def test_cfg4_full_size_randomized(K):
     torch.cuda.empty_cache()
 
 
+# ---------------------------------------------------------------- K7L one-sided Jacobi SVD
+@pytest.mark.parametrize("n", [2, 9, 97, 128, 250, 312, 513, 936, 1024])
+def test_eigh_large_matches_lapack(K, n):
+    """The multi-workgroup one-sided Jacobi kernel behind `_eigh_desc` for 96 < n <= 1024, on the
+    same graded matrices as K7's test (eigenvalues over 12 decades): eigenvalues to 1e-13 of the
+    largest, V orthonormal to 1e-13, A V = V diag(w) to 1e-13 |A| -- times n / 128 beyond n = 128."""
+    from dmd_era5_amd import svd as dsvd
+
+    rs = np.random.RandomState(n)
+    Qm, _ = np.linalg.qr(rs.standard_normal((n, n)))
+    lam = 10.0 ** np.linspace(6, -6, n)
+    A = (Qm * lam) @ Qm.T
+    A = 0.5 * (A + A.T)
+    L = np.linalg.cholesky(A)
+    sig, Zt = K.svd_jacobi(_dev(L.T))
+    assert 1 <= K.last_jacobi_sweeps <= 20
+    w, V = (sig * sig).cpu().numpy(), Zt.cpu().numpy().T
+    ref = np.linalg.eigvalsh(A)[::-1]
+    # K7's bounds (1e-13) up to n = 128, growing like n beyond: the Cholesky factor handed in,
+    # LAPACK's reference values and the sums over n terms all carry ~n eps (n = 936: 7e-13)
+    bound = 1e-13 * max(1.0, n / 128.0)
+    assert np.all(np.diff(w) <= 0)
+    assert np.abs(w - ref).max() <= bound * ref[0]
+    assert np.abs(V.T @ V - np.eye(n)).max() <= bound
+    assert np.abs(A @ V - V * w).max() <= bound * ref[0]
+    if n > 96:
+        w2, V2 = dsvd._eigh_desc(_dev(A), K)            # the route the Rayleigh-Ritz steps take
+        assert np.abs(w2.cpu().numpy() - ref).max() <= bound * ref[0]
+        assert np.abs(A @ V2.cpu().numpy() - V2.cpu().numpy() * w2.cpu().numpy()).max() <= bound * ref[0]
+
+
+def test_svd_jacobi_relative_accuracy_and_zero_columns(K):
+    """Singular values over 14 decades come out with RELATIVE accuracy (what the graded refinement
+    matrix needs and syevd / gesvd do not promise) -- checked against a 40-digit mpmath SVD --,
+    rank-deficient input gives zero singular values with zero vectors, and an indefinite
+    Rayleigh-Ritz matrix takes the shifted route."""
+    from dmd_era5_amd import svd as dsvd
+
+    mpmath = pytest.importorskip("mpmath")
+    rs = np.random.RandomState(3)
+    # C = B D, B well conditioned, D graded: the orientation one-sided Jacobi (rotations from the
+    # right) resolves with relative accuracy -- and the one the engine hands it (C = S L, L ~ I)
+    n0 = 48
+    d0 = np.logspace(3, -11, n0)
+    C0 = (np.eye(n0) + 0.05 * rs.standard_normal((n0, n0))) * d0[None, :]
+    mpmath.mp.dps = 40
+    exact = np.array([float(x) for x in mpmath.svd_r(mpmath.matrix(C0.tolist()), compute_uv=False)])
+    sig, Zt = K.svd_jacobi(_dev(C0.T))
+    assert np.abs(sig.cpu().numpy() / np.sort(exact)[::-1] - 1).max() < 1e-13          # every one of them
+    n = 200
+    s_true = np.logspace(3, -11, n)
+    Cm = (np.eye(n) + 0.05 * rs.standard_normal((n, n))) * s_true[None, :]
+    sig, Zt = K.svd_jacobi(_dev(Cm.T))
+    sig = sig.cpu().numpy()
+    assert np.abs(sig[:100] / np.linalg.svd(Cm, compute_uv=False)[:100] - 1).max() < 1e-9
+    Z = Zt.cpu().numpy().T
+    assert np.abs(Z.T @ Z - np.eye(n)).max() < 1e-13
+    # left singular vectors: Z^T C has orthogonal rows of norm sigma
+    R = Z.T @ Cm                                      # (numpy's product resolves the leading rows only)
+    assert np.abs(np.linalg.norm(R, axis=1)[:60] / sig[:60] - 1).max() < 1e-11
+    # rank deficiency
+    Cz = Cm.copy()
+    Cz[:, 150:] = 0.0
+    sig, Zt = K.svd_jacobi(_dev(Cz.T))
+    assert float(sig[150:].abs().max()) == 0.0 and float(Zt[150:].abs().max()) == 0.0
+    assert float((Zt[:150] @ Zt[:150].T - torch.eye(150, dtype=torch.float64, device="cuda")).abs().max()) < 1e-13
+    # an indefinite matrix through _eigh_desc: shift, factor, shift back
+    A = rs.standard_normal((160, 160))
+    A = A @ A.T
+    A[-1, -1] -= 1e-9 * np.abs(A).max() + np.linalg.eigvalsh(A)[0]      # smallest eigenvalue just below zero
+    w, V = dsvd._eigh_desc(_dev(A), K)
+    ref = np.linalg.eigvalsh(A)[::-1]
+    assert np.abs(w.cpu().numpy() - ref).max() <= 1e-12 * ref[0]
+
+
 # ---------------------------------------------------------------- K8 fp64 symmetric product
 @pytest.mark.parametrize("n,b,shift", [(2, 2, 0.0), (34, 2, 0.5), (256, 32, 0.0), (258, 34, -1.25), (1000, 78, 3.0),
                                         (1500, 124, 0.0), (1024, 130, 7.5), (2050, 312, 1e3), (8760, 78, 2.0)])

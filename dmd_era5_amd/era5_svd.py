@@ -171,7 +171,15 @@ def svd_on_era5(da, parsed_config: dict):
         log_and_print(logger, "Performing randomized SVD...")
     else:
         raise ValueError(f"SVD type {svd_type} is not supported.")
+    if getattr(X, "dtype", None) == np.float64:
+        log_and_print(logger, "Input is float64: the engine computes in fp32 on the MFMA units (the reference's "
+                              "ERA5 slices are float32) and returns float64 arrays that carry ~1e-6 relative "
+                              "accuracy, not LAPACK's 1e-12.", level="warning")
     U, s, V = svd_numpy(X, svd_type, n_components, **_engine_opts(parsed_config))
+    if s.size and float(s[0]) > 0 and float(s[-1]) <= 1e-7 * float(s[0]):
+        log_and_print(logger, "Singular values below 1e-7 s_1 are under the fp32 resolution of the data: their "
+                              "columns of U are returned as zeros (LAPACK returns arbitrary orthonormal "
+                              "vectors there).", level="warning")
     log_and_print(logger, f"{svd_type.capitalize()} SVD complete.")
     return U, s, V
 
@@ -218,6 +226,38 @@ def plan_selection(ds: Dataset, levels, delta_time):
         raise ValueError("Start datetime must be before end datetime.")
     labels, take = nearest_resample_index(times, delta_time)
     return level_idx, np.asarray(levels), take, labels
+
+
+def _resident_reserve_bytes(rows: int, n: int, d: int, k: int, svd_type: str, kern) -> int:
+    """HBM the resident path needs NEXT TO the snapshot matrix, from the problem's own sizes (a
+    fixed 12 GB used to be added: it refused small slices on small cards and under-reserved cfg3's
+    rank 200): the fp64 Gram and the dense pieces of the eigen stage (standard), the partial-tile
+    workspace of the batched Gram / product launch as the library itself sizes it, the m x l basis
+    and the m x k result (fp32), the two pinned-slab-sized device staging buffers of the ingest,
+    and 1 GiB of slack for the allocator."""
+    nd = max(1, n - d + 1)
+    l = min(nd, k + max(8, k // 4)) if svd_type == "standard" else min(nd, k + 20)
+    out = 2 * SLAB_BYTES + (1 << 30)
+    out += 4 * rows * d * (l + k)                                   # U' / Y and U
+    if svd_type == "standard":
+        out += 3 * 8 * n * n                                        # G, the deflated / shifted copy, K8 partials
+        out += 8 * 8 * nd * 2 * l                                   # blocks of the eigen stage
+    else:
+        out += 4 * rows * d * l                                     # Q next to Y in the range finder
+    try:
+        import ctypes as C
+
+        from .svd import split_rows
+
+        ms = [b - a for a, b in split_rows(rows)][:16]
+        arr = (C.c_int64 * len(ms))(*ms)
+        if svd_type == "standard":
+            out += int(kern._lib.dmdx_syrk_blocks_workspace_bytes(arr, len(ms), n))
+        else:
+            out += int(kern._lib.dmdx_gemm_tn_blocks_workspace_bytes(arr, len(ms), n, l))
+    except Exception:
+        out += 8 << 30                                              # a provider without the C ABI (tests)
+    return int(out)
 
 
 def lat_band(nlat: int, rank: int, world: int) -> tuple[int, int]:
@@ -365,8 +405,11 @@ def _device_pipeline(ds: Dataset, parsed_config: dict, comm=None, kern=None, dev
     if device.type == "cuda" and not stream_bytes:
         # X should be resident: find out before the allocator does
         rows = len(names) * nlev * ((band[1] - band[0]) if band else nlat) * nlon
-        need = 4 * rows * len(take) + (12 << 30)          # X + Gram workspace / U / small dense pieces
-        free = torch.cuda.mem_get_info(device)[0]
+        reserve = _resident_reserve_bytes(rows, len(take), d, k, parsed_config["svd_type"], kern)
+        need = 4 * rows * len(take) + reserve
+        # free HBM = what the driver reports + what torch's allocator holds cached but unused
+        free = torch.cuda.mem_get_info(device)[0] + max(
+            0, torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device))
         fits = need <= free
         if comm.world_size > 1:   # one decision for all ranks: the resident and the streaming path exchange differently
             flags = comm.allgather(torch.tensor([1 if fits else 0], dtype=torch.int64, device=device))
@@ -375,7 +418,7 @@ def _device_pipeline(ds: Dataset, parsed_config: dict, comm=None, kern=None, dev
             if can_stream:
                 stream_bytes = max(1 << 30, min(free // 3, 32 << 30))
             else:
-                ranks = -(-4 * len(names) * nlev * nlat * nlon * len(take) // max(free - (12 << 30), 1 << 30))
+                ranks = -(-4 * len(names) * nlev * nlat * nlon * len(take) // max(free - reserve, 1 << 30))
                 raise MemoryError(
                     f"the snapshot matrix of this rank ({rows} x {len(take)} fp32 = {4 * rows * len(take) / 1e9:.1f} GB) "
                     f"does not fit the {free / 1e9:.1f} GB of free HBM; shard the space points over more GPUs: "
@@ -643,19 +686,6 @@ def main(config: dict | None = None, write_to_netcdf: bool = False, use_dvc: boo
             log_and_print(logger, msg, "error")
             raise Exception(msg) from e
     return svd_results, False, False
-
-
-# host-only reference pipeline (numpy pre-processing + svd_on_era5), kept for small inputs
-# and as the readable statement of what _device_pipeline computes
-def host_pipeline(ds: Dataset, parsed_config: dict):
-    if parsed_config["mean_center"]:
-        ds, ds_mean, ds_std = standardize_data(ds, scale=parsed_config["scale"])
-    else:
-        ds_mean = ds_std = None
-    da = flatten_era5_variables(ds)
-    da = apply_delay_embedding(da, parsed_config["delay_embedding"])
-    U, s, V = svd_on_era5(da, parsed_config)
-    return U, s, V, da
 
 
 if __name__ == "__main__":

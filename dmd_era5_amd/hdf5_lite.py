@@ -96,6 +96,7 @@ def _bind(lib, hl):
 
     p_hs = C.POINTER(hsize_t)
     f(lib, "H5open", herr_t)
+    f(lib, "H5get_libversion", herr_t, C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.POINTER(C.c_uint))
     f(lib, "H5Eset_auto2", herr_t, hid_t, C.c_void_p, C.c_void_p)
     f(lib, "H5Fcreate", hid_t, C.c_char_p, C.c_uint, hid_t, hid_t)
     f(lib, "H5Fopen", hid_t, C.c_char_p, C.c_uint, hid_t)
@@ -226,6 +227,7 @@ class Writer:
             raise OSError(f"H5Fcreate failed for {path}")
         self._dsets: dict[str, int] = {}
         self._vardims: dict[str, tuple] = {}
+        self._has_ncproperties = False
 
     def __enter__(self):
         return self
@@ -283,6 +285,8 @@ class Writer:
         lib = self.lib
         loc = self.fid if name is None else self._dsets[name]
         for key, val in attrs.items():
+            if name is None and key == "_NCProperties":
+                self._has_ncproperties = True
             if isinstance(val, (bool, np.bool_)):
                 val = int(val)
             if isinstance(val, (list, tuple)) and len(val) == 1 and isinstance(val[0], str):
@@ -353,6 +357,15 @@ class Writer:
             for i, dn in enumerate(dims):
                 if dn in self._dsets:
                     hl.H5DSattach_scale(self._dsets[v], self._dsets[dn], i)
+        # what netCDF-C adds to its own files: the dimension id on every dimension scale (it
+        # orders the dimensions by it instead of by creation order) and the provenance string
+        for i, dn in enumerate(dim_names):
+            if dn in self._dsets:
+                self.attrs(dn, {"_Netcdf4Dimid": np.int32(i)})
+        if not self._has_ncproperties:
+            maj, mnr, rel = C.c_uint(0), C.c_uint(0), C.c_uint(0)
+            lib.H5get_libversion(C.byref(maj), C.byref(mnr), C.byref(rel))
+            self.attrs(None, {"_NCProperties": f"version=2,dmd_era5_amd_hdf5_lite=1,hdf5={maj.value}.{mnr.value}.{rel.value}"})
         for did in self._dsets.values():
             lib.H5Dclose(did)
         lib.H5Fclose(self.fid)
@@ -643,6 +656,25 @@ class Reader:
                 lib.H5Sclose(fsp)
                 lib.H5Sclose(msp)
             lib.H5Dclose(did)
+
+    def attr_names(self, name: str | None = None) -> list[str]:
+        """Names of ALL attributes of a dataset / of the file, including the ones whose types this
+        reader does not decode (the object-reference lists of the dimension-scale API)."""
+        lib = self.lib
+        loc = self.fid if name is None else lib.H5Dopen2(self.fid, name.encode(), _H5P_DEFAULT)
+        out, i = [], 0
+        buf = C.create_string_buffer(1024)
+        while True:
+            aid = lib.H5Aopen_by_idx(loc, b".", _H5_INDEX_NAME, _H5_ITER_INC, i, _H5P_DEFAULT, _H5P_DEFAULT)
+            if aid < 0:
+                break
+            i += 1
+            lib.H5Aget_name(aid, 1024, buf)
+            out.append(buf.value.decode())
+            lib.H5Aclose(aid)
+        if name is not None:
+            lib.H5Dclose(loc)
+        return out
 
     def attrs(self, name: str | None = None, raw: bool = False) -> dict:
         lib = self.lib

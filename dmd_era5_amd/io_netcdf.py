@@ -3,17 +3,20 @@
 ``(time, level, latitude, longitude)``, attrs source_path / variables / levels / ...) and
 the SVD result ``data/era5_svd/*.nc`` (ref: era5_svd.py:434, README.md:97-119).
 
-Backends, probed at run time:
-  1. ``netCDF4`` (present wherever the reference itself is installed) -> NETCDF4/HDF5,
-     the reference's format;
-  2. :mod:`dmd_era5_amd.hdf5_lite` -- our ctypes binding of libhdf5 -> NETCDF4/HDF5 as well
-     (datasets + dimension scales + attributes, the layout netCDF-C reads), with lazy variables
-     and time-slab reads for the streaming ingest.  This is what runs in this image
-     (libhdf5 1.10.6 under /opt/conda/lib);
-  3. ``scipy.io.netcdf_file`` -> NetCDF-3 64-bit-offset, when no HDF5 library can be found.
+Backends:
+  1. :mod:`dmd_era5_amd.hdf5_lite` -- our ctypes binding of libhdf5 -> NETCDF4/HDF5, the
+     reference's format (datasets + dimension scales with ``_Netcdf4Dimid`` + attributes +
+     ``_NCProperties``: the objects netCDF-C looks for; CF ``coordinates`` attributes as xarray
+     writes them), with lazy variables and time-slab reads for the streaming ingest.  The default
+     and the tested one (libhdf5 1.10.6 under /opt/conda/lib in this image).  No netCDF library
+     is importable here, so what netCDF-C / xarray make of these files is **interop parity
+     unpinned**; tests/test_host_mirror.py pins the HDF5 structure instead;
+  2. ``scipy.io.netcdf_file`` -> NetCDF-3 64-bit-offset, when no HDF5 library can be found.
      Same variables / dimensions / attributes; limits of the classic format apply (< 4 GiB per
-     variable, no string variables: ``original_variable`` is stored as an index + flag_meanings).
-``DMDX_NETCDF_BACKEND`` = netcdf4 | hdf5 | scipy forces one (tests).
+     variable, no string variables: ``original_variable`` is stored as an index + flag_meanings);
+  3. ``netCDF4`` -- only on request (``DMDX_NETCDF_BACKEND=netcdf4``): that path has never run
+     (the module is not importable in this image).
+``DMDX_NETCDF_BACKEND`` = hdf5 | scipy | netcdf4 forces one.
 """
 from __future__ import annotations
 
@@ -85,9 +88,17 @@ def _backend() -> str:
     forced = os.environ.get("DMDX_NETCDF_BACKEND", "").lower()
     if forced in ("netcdf4", "hdf5", "scipy"):
         return forced
-    if _have_netcdf4():
-        return "netcdf4"
     return "hdf5" if hdf5_lite.available() else "scipy"
+
+
+def _coordinates_attr(ds: Dataset, da) -> str | None:
+    """The CF ``coordinates`` attribute xarray's ``to_netcdf`` (reference era5_svd.py:434) puts on
+    a variable: the non-index coordinates that live on its dimensions (level, latitude,
+    longitude, original_variable, delay for everything with a ``space`` dimension), sorted, space
+    separated.  A reader (xarray's decoder, ours) takes exactly these for coordinates."""
+    names = sorted(n for n, c in ds.coords.items()
+                   if c.dims != (n,) and getattr(c.values, "ndim", 1) == 1 and set(c.dims) <= set(da.dims))
+    return " ".join(names) if names else None
 
 
 def to_netcdf(ds: Dataset, path: str) -> str:
@@ -115,7 +126,11 @@ def _write_hdf5(ds: Dataset, path: str) -> None:
                 continue  # (m, 3) space labels: stored as level / latitude / longitude
             w.dataset(name, vals, c.dims, attrs)
         for name, da in ds.data_vars.items():
-            w.dataset(name, np.asarray(da.values), da.dims, {k: v for k, v in da.attrs.items()})
+            attrs = {k: v for k, v in da.attrs.items()}
+            cattr = _coordinates_attr(ds, da)
+            if cattr:
+                attrs["coordinates"] = cattr
+            w.dataset(name, np.asarray(da.values), da.dims, attrs)
         w.attrs(None, dict(ds.attrs))
 
 
@@ -136,7 +151,11 @@ def _prepared_vars(ds: Dataset):
             continue  # the (m, 3) space labels are stored as level/latitude/longitude instead
         out.append((name, c.dims, vals, attrs))
     for name, da in ds.data_vars.items():
-        out.append((name, da.dims, np.asarray(da.values), dict(da.attrs)))
+        attrs = dict(da.attrs)
+        cattr = _coordinates_attr(ds, da)
+        if cattr:
+            attrs["coordinates"] = cattr
+        out.append((name, da.dims, np.asarray(da.values), attrs))
     return out
 
 
@@ -199,6 +218,19 @@ _ROW_COORDS = ("level", "latitude", "longitude", "original_variable", "delay")
 
 
 def _assemble(raw: dict, dimsizes: dict, gattrs: dict) -> Dataset:
+    """Variables -> Dataset.  Coordinates are the 1-D variables named like their dimension plus
+    whatever the variables' CF ``coordinates`` attributes name (what xarray writes and decodes by);
+    files without such attributes (older results of this package) fall back to the fixed list of
+    per-row labels of an SVD result."""
+    def _s(v):
+        return v.decode() if isinstance(v, bytes) else str(v)
+
+    listed = set()
+    for _, (_, _, attrs) in raw.items():
+        if "coordinates" in attrs:
+            listed.update(_s(attrs["coordinates"]).split())
+    if "coordinates" in gattrs:
+        listed.update(_s(gattrs["coordinates"]).split())
     coords, data = {}, {}
     for name, (dims, vals, attrs) in raw.items():
         if "units" in attrs and " since " in str(attrs["units"]) and not isinstance(vals, LazyArray):
@@ -207,11 +239,15 @@ def _assemble(raw: dict, dimsizes: dict, gattrs: dict) -> Dataset:
             fm = attrs["flag_meanings"]
             names = (fm.decode() if isinstance(fm, bytes) else fm).split(" ")
             vals = np.array([names[i] for i in vals])
-        is_coord = (dims == (name,)) or (name in _ROW_COORDS and dims == ("space",) and "space" in dimsizes
-                                         and "U" in raw)
+        if listed:
+            is_coord = (dims == (name,)) or name in listed
+        else:
+            is_coord = (dims == (name,)) or (name in _ROW_COORDS and dims == ("space",) and "space" in dimsizes
+                                             and "U" in raw)
+        attrs = {k: v for k, v in attrs.items() if k != "coordinates"}
         (coords if is_coord else data)[name] = (dims, vals, attrs)
     cds = {k: Coord(d, v) for k, (d, v, _) in coords.items()}
-    ds = Dataset(coords=cds, attrs=gattrs)
+    ds = Dataset(coords=cds, attrs={k: v for k, v in gattrs.items() if k != "coordinates"})
     for k, (d, v, a) in data.items():
         ds[k] = DataArray(v, d, {c: cds[c] for c in cds if set(cds[c].dims) <= set(d)}, a)
     return ds

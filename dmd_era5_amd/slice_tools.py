@@ -228,7 +228,13 @@ def space_coord_to_level_lat_lon(ds: Dataset) -> Dataset:
     sp = np.asarray(ds.coords["space"].values)
     if sp.dtype == object:  # tuples, as the reference builds them
         sp = np.array([tuple(x) for x in sp], dtype=np.float64)
-    new = {"level": Coord("space", sp[:, 0]), "latitude": Coord("space", sp[:, 1]),
+    level = sp[:, 0]
+    if level.size and np.all(level == np.round(level)):
+        # the reference takes the labels out of the (level, lat, lon) tuples of its MultiIndex, so
+        # `level` keeps the integer dtype of the ERA5 pressure levels (int64 in the result file,
+        # media/svd_netcdf_contents.png); the (m, 3) label array used here is float64 throughout
+        level = level.astype(np.int64)
+    new = {"level": Coord("space", level), "latitude": Coord("space", sp[:, 1]),
            "longitude": Coord("space", sp[:, 2]), "space": Coord("space", np.arange(sp.shape[0], dtype=np.int64))}
     ds.coords.update(new)
     for da in ds.data_vars.values():

@@ -379,3 +379,108 @@ def test_hdf5_label_coordinates_with_millions_of_strings(tmp_path):
             assert got.shape == ref.shape and np.array_equal(got, ref), name
     uq, inv = hdf5_lite._factorize(runs)
     assert np.array_equal(uq[inv], runs) and len(uq) == 3
+
+
+def test_svd_result_file_has_the_hdf5_objects_netcdf_c_requires(svd_base_config, project_root, monkeypatch):
+    """a12 / f-2: `svd_results.to_netcdf(save_path, format="NETCDF4")` (reference era5_svd.py:434).
+    No netCDF library is importable in this image, so what netCDF-C / xarray make of the file is
+    INTEROP PARITY UNPINNED; pinned instead is the HDF5 structure a NETCDF4 file consists of, walked
+    object by object: the provenance attribute, one dimension scale per dimension (CLASS, NAME,
+    _Netcdf4Dimid, back-references), the netCDF placeholder naming for dimensions without a
+    coordinate variable, DIMENSION_LIST on every variable, fixed-length text attributes, the
+    coordinate dtypes of the reference's result schema (media/svd_netcdf_contents.png: int64
+    components / space / delay / level, float64 latitude / longitude, strings for
+    original_variable, float32 data), and the CF `coordinates` attribute xarray adds -- from which
+    (not from a fixed list) the reader then rebuilds the same coordinate set as the README's schema."""
+    from dmd_era5_amd import hdf5_lite
+    from dmd_era5_amd.era5_svd import add_config_attributes, combine_svd_results
+
+    if not hdf5_lite.available():
+        pytest.skip("libhdf5 not found")
+    monkeypatch.setenv("DMDX_NETCDF_BACKEND", "hdf5")
+    p = config_parser(dict(svd_base_config, start_datetime="2019-01-01T00", end_datetime="2019-01-02T00",
+                           variables="temperature,u_component_of_wind", levels="1000,850", n_components=5,
+                           mean_center=True, scale=True), "era5-svd")
+    ds = create_mock_era5("2019-01-01", "2019-01-02", ["temperature", "u_component_of_wind"], [1000, 850],
+                          seed=5, dtype=np.float32)
+    c, mu, sd = st.standardize_data(ds, scale=True)
+    da = st.apply_delay_embedding(st.flatten_era5_variables(c), 2)
+    m = da.shape[0]
+    U, s, V = np.linalg.svd(da.values, full_matrices=False)
+    from dmd_era5_amd.labeled import DataArray, Dataset
+
+    row = {k: da.coords[k] for k in ("space", "original_variable", "delay")}
+    Xm = DataArray(np.tile(st.flatten_era5_variables(mu).values, 2).astype(np.float32), ("space",), row)
+    Xs = DataArray(np.tile(st.flatten_era5_variables(sd).values, 2).astype(np.float32), ("space",), row)
+    res = combine_svd_results(U[:, :5].astype(np.float32), s[:5].astype(np.float32), V[:5].astype(np.float32),
+                              da.coords, X=da, X_mean=Xm, X_std=Xs)
+    res = st.space_coord_to_level_lat_lon(add_config_attributes(res, p))
+    assert io_netcdf.to_netcdf(res, p["save_path"]) == "hdf5-lite"
+
+    with hdf5_lite.Reader(p["save_path"]) as r:
+        g = r.attrs(None, raw=True)
+        assert g["_NCProperties"].startswith("version=2,") and "hdf5=" in g["_NCProperties"]
+        # global attributes: the eleven of add_config_attributes (era5_svd.py:55-65); text as
+        # fixed-length strings, flags as integers, lists of str as 1-D string arrays
+        assert g["svd_type"] == "randomized" and g["n_components"] == 5 and g["mean_center"] == 1 and g["scale"] == 1
+        assert list(g["variables"]) == ["temperature", "u_component_of_wind"] and list(g["levels"]) == [1000, 850]
+        assert {"source_path", "delay_embedding", "era5_slice_path", "date_processed", "save_data_matrix"} <= set(g)
+        dims = {"space": m, "components": 5, "time": da.shape[1]}
+        ids = {}
+        for d, n in dims.items():                              # one dimension scale each
+            shape, dt, vdims = r.variables[d]
+            a = r.attrs(d, raw=True)
+            assert shape == (n,) and vdims == (d,)
+            assert a["CLASS"] == "DIMENSION_SCALE" and a["NAME"] == d      # a coordinate variable, not a placeholder
+            assert "REFERENCE_LIST" in r.attr_names(d)                      # variables are attached to it
+            ids[d] = a["_Netcdf4Dimid"]
+        assert sorted(ids.values()) == [0, 1, 2]
+        for v, vd in {"U": ("space", "components"), "s": ("components",), "V": ("components", "time"),
+                      "X": ("space", "time"), "X_mean": ("space",), "X_std": ("space",)}.items():
+            shape, dt, vdims = r.variables[v]
+            assert vdims == vd and dt == np.float32 or v in ("X_mean", "X_std", "X")
+            assert vdims == vd and "DIMENSION_LIST" in r.attr_names(v)
+            a = r.attrs(v)
+            if "space" in vd:
+                assert a["coordinates"] == "delay latitude level longitude original_variable"
+            else:
+                assert "coordinates" not in a
+        for cname, kind in {"components": "i", "space": "i", "delay": "i", "level": "i",
+                            "latitude": "f", "longitude": "f"}.items():
+            shape, dt, vdims = r.variables[cname]
+            assert dt.kind == kind and dt.itemsize == 8, (cname, dt)
+        assert r.variables["original_variable"][1] == "str" or isinstance(r.variables["original_variable"][1], str)
+        assert r.variables["time"][1].kind in "if" and "units" in r.attrs("time") \
+            and " since " in r.attrs("time")["units"]
+        for cname in ("delay", "level", "latitude", "longitude", "original_variable"):
+            assert r.variables[cname][2] == ("space",) and "DIMENSION_LIST" in r.attr_names(cname)
+
+    # a dimension without a coordinate variable gets netCDF-C's placeholder scale
+    bare = Dataset(coords={}, attrs={"title": "t"})
+    bare["field"] = DataArray(np.zeros((3, 4), dtype=np.float32), ("a", "b"), {}, {})
+    path = str(project_root / "bare.nc")
+    io_netcdf.to_netcdf(bare, path)
+    with hdf5_lite.Reader(path) as r:
+        for d, n in (("a", 3), ("b", 4)):
+            a = r.attrs(d, raw=True)
+            assert a["CLASS"] == "DIMENSION_SCALE" and r.is_placeholder_dimension(d)
+            assert a["NAME"] == f"This is a netCDF dimension but not a netCDF variable.{n:>10d}"
+            assert "_Netcdf4Dimid" in a
+
+    # the reader classifies coordinates from the `coordinates` attributes (as xarray's decoder
+    # does), and arrives at the README's schema: coordinates vs data variables
+    back = io_netcdf.open_dataset(p["save_path"])
+    assert sorted(back.coords) == sorted(["components", "space", "time", "delay", "level", "latitude", "longitude",
+                                          "original_variable"])
+    assert sorted(back.data_vars) == ["U", "V", "X", "X_mean", "X_std", "s"]
+    assert sorted(back["U"].coords) == sorted(["components", "space", "delay", "level", "latitude", "longitude",
+                                               "original_variable"])
+    assert "coordinates" not in back["U"].attrs
+    # a variable NOT named in any `coordinates` attribute stays a data variable even if it is
+    # called like a row label and lives on `space`
+    odd = Dataset(coords={"space": res.coords["space"]}, attrs={})
+    odd["delay"] = DataArray(np.arange(m, dtype=np.int64), ("space",), {}, {})
+    odd["U"] = DataArray(np.zeros((m, 2), dtype=np.float32), ("space", "components"), {}, {"coordinates": "space"})
+    path2 = str(project_root / "odd.nc")
+    io_netcdf.to_netcdf(odd, path2)
+    assert "delay" in io_netcdf.open_dataset(path2).data_vars

@@ -173,27 +173,29 @@ def embed_view(Xt: torch.Tensor, d: int) -> torch.Tensor:
 # ---------------------------------------------------------------------------
 # small dense pieces (fp64, torch)
 # ---------------------------------------------------------------------------
-def _orth(Y: torch.Tensor, rounds: int = 2) -> torch.Tensor:
+def _orth(Y: torch.Tensor, rounds: int = 2, _shifted: bool = False) -> torch.Tensor:
     """Orthonormal basis of the columns of a tall fp64 block.  CholeskyQR2 (two rounds of
     Gram -> Cholesky -> triangular solve: three small GEMM-type calls, ~1 ms at 8760 x 210)
     instead of Householder QR (rocSOLVER geqrf+orgqr: ~9 ms).  A block too ill-conditioned for
     the plain Gram route (cond > ~1e8: G times a random block of a low-rank + noise matrix spans
-    lambda_1 / lambda_noise) first gets a *shifted* round (Fukaya et al. 2020: factor
-    Y^T Y + s I, s ~ 1e-11 |Y|^2, which caps the conditioning of what the plain rounds then see),
-    and only if that fails too Householder QR.  ``rounds=1``: conditioning control between the
-    factors of a polynomial filter (orthogonal to ~cond^2 eps), not an orthonormal basis."""
+    lambda_1 / lambda_noise) first gets ONE *shifted* round (Fukaya et al. 2020: factor
+    Y^T Y + s I, s ~ 1e-11 |Y|^2, which caps the conditioning of what the plain rounds then see);
+    if the plain rounds fail again behind it (an exactly rank-deficient block: a constant
+    matrix) Householder QR takes over.  ``rounds=1``: conditioning control between the factors
+    of a polynomial filter (orthogonal to ~cond^2 eps), not an orthonormal basis."""
     Q = Y
     for it in range(rounds):
         G = Q.T @ Q
         L, err = torch.linalg.cholesky_ex(G)
         if int(err) != 0 or not torch.isfinite(L).all():
-            if it == 0:
+            if it == 0 and not _shifted:
                 tr = torch.diagonal(G).sum()
+                eye = torch.eye(G.shape[0], dtype=G.dtype, device=G.device)
                 for rel in (1e-11, 1e-8):
-                    L, err = torch.linalg.cholesky_ex(G + (rel * tr) * torch.eye(G.shape[0], dtype=G.dtype, device=G.device))
+                    L, err = torch.linalg.cholesky_ex(G + (rel * tr) * eye)
                     if int(err) == 0 and bool(torch.isfinite(L).all()):
                         Qs = torch.linalg.solve_triangular(L, Q.T, upper=False).T
-                        return _orth(Qs, rounds=2) if rel == 1e-11 else _orth(_orth(Qs, rounds=1), rounds=2)
+                        return _orth(Qs, rounds=max(rounds, 2) + (1 if rel == 1e-8 else 0), _shifted=True)
             Qh, _ = torch.linalg.qr(Y, mode="reduced")
             return Qh
         Q = torch.linalg.solve_triangular(L, Q.T, upper=False).T

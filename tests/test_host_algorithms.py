@@ -341,3 +341,15 @@ def test_extreme_magnitudes_are_rescaled(scale):
         r = fn(Xt, 6, kern=K, **kw)
         assert "rescaled_by" in r.info and torch.equal(Xt, keep)
         assert np.allclose(r.s.numpy(), sref, rtol=1e-5)
+
+
+def test_orth_on_exactly_rank_deficient_blocks_ends_in_householder():
+    """A constant matrix (found by the GPU suite: RecursionError): every Gram, shifted or not,
+    stays singular behind the shifted round -- the fallback must end, not recurse."""
+    Y = torch.ones((50, 6), dtype=torch.float64)
+    Q = dsvd._orth(Y)
+    assert Q.shape == (50, 6) and bool(torch.isfinite(Q).all())
+    one = Y[:, :1] / Y[:, :1].norm()
+    assert float((one - Q @ (Q.T @ one)).abs().max()) < 1e-12          # the one direction Y has is in span(Q)
+    Z = torch.zeros((40, 3), dtype=torch.float64)
+    assert bool(torch.isfinite(dsvd._orth(Z)).all())

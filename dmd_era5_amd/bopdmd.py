@@ -16,9 +16,10 @@ the Gauss-Newton matrix and gradient of the full Golub-Pereyra Jacobian reduce t
         J^H J = [(P W)^H (P W)] o [conj(B) B^T]  +  [V S^-2 V^H]^T-type term o [conj(C) C^T]
         J^H rho = -g ,   g_j = sum_s C[j, s] conj(B[j, s]) ,        P = I - U U^H
 
-so one iteration costs an economy SVD of the n x r matrix Phi and a handful of (n x r)^H (n x r)
-products -- all dense torch ops on whatever device H lives on (fp64/complex128 by default; this is
-a few-hundred-microsecond-per-iteration problem at n = 8760, r = 200, not a roofline kernel).
+so one iteration costs an orthonormal basis of the n x r matrix Phi (CholeskyQR2; the economy SVD
+only when Phi is too ill-conditioned for it) and a handful of (n x r)^H (n x r) products -- all
+dense torch ops on whatever device H lives on (complex128 by default; launch-bound small dense
+work at n = 8760, r = 200, not a roofline kernel).
 Initial eigenvalues come from the trapezoidal-rule DMD of the same data (Askham & Kutz section 3.3).
 ``num_trials > 0`` adds the bagging of BOP-DMD (Sashidhar & Kutz 2022): refits on random subsets
 of the snapshots, eigenvalue mean / std over the trials.
@@ -111,31 +112,71 @@ def initial_eigs(H: torch.Tensor, t: torch.Tensor, r: int) -> torch.Tensor:
     return trapezoidal_dmd_eigs(H128, tr.to(torch.complex128), r)
 
 
-def _project(alpha, t, H, rank_tol=None):
-    """B(alpha), residual and the SVD pieces of Phi(alpha) (all in H's dtype; alpha complex128).
-    Returns None when Phi is not finite (a trial step into Re(alpha) t > the dtype's range)."""
+def _project(alpha, t, H, rank_tol=None, use_qr: bool = True):
+    """Variable projection at alpha: (Phi, Q, Ginv, B, R) with Q an orthonormal basis of
+    range(Phi), Ginv = (Phi^H Phi)^-1, B = Phi^+ H and R = H - Phi B -- all in H's dtype (alpha
+    complex128).  Returns None when Phi is not finite (a trial step into Re(alpha) t > the dtype's
+    range).
+
+    Route (round 2): CholeskyQR2 of Phi -- two r x r Grams accumulated in complex128, two
+    Cholesky factorisations, two triangular solves: ~10 small launches, ~2 ms at n = 8760,
+    r = 200 -- instead of the economy SVD (rocSOLVER gesvd of the 8760 x 200 matrix: ~90 ms of
+    launch-bound time per evaluation, i.e. the whole iteration).  Exponentials whose frequencies
+    are separated by more than ~1 / T are nearly orthogonal, which is the regime of the fit; when
+    the basis is too ill-conditioned for the Gram route (Cholesky fails, or the factor's diagonal
+    spans more than 1 / rank_tol) the SVD route takes over, with its truncation of the null
+    directions."""
     Phi = _phi(alpha, t, H.dtype)
     if not bool(torch.isfinite(Phi.real).all() and torch.isfinite(Phi.imag).all()):
         return None
     if rank_tol is None:
         rank_tol = 1e-12 if H.dtype == torch.complex128 else 1e-6
+    if use_qr:
+        Q, Rt = Phi, None
+        ok = True
+        for _ in range(2):
+            Qd = Q.to(torch.complex128)          # the r x r Gram in complex128 whatever the working dtype:
+            G = Qd.conj().T @ Qd                  # fp32 sums would cap the usable cond(Phi) at ~3e3
+            L, err = torch.linalg.cholesky_ex(G)
+            d = torch.diagonal(L).real
+            if int(err) != 0 or not bool(torch.isfinite(d).all()) or float(d.min()) < math.sqrt(rank_tol) * float(d.max()):
+                ok = False
+                break
+            Rk = L.conj().T                                           # Q_old = Q_new Rk
+            Q = torch.linalg.solve_triangular(Rk.to(H.dtype), Q, upper=True, left=False)
+            Rt = Rk if Rt is None else Rk @ Rt
+        if ok:
+            Rinv = torch.linalg.solve_triangular(Rt, torch.eye(Rt.shape[0], dtype=Rt.dtype, device=Rt.device), upper=True)
+            QhH = Q.conj().T @ H
+            B = Rinv.to(H.dtype) @ QhH
+            R = H - Q @ QhH
+            Ginv = (Rinv @ Rinv.conj().T).to(H.dtype)
+            return Phi, Q, Ginv, B, R
     U, S, Vh = torch.linalg.svd(Phi, full_matrices=False)
     keep = int((S > S[0] * rank_tol).sum())
     U, S, Vh = U[:, :keep], S[:keep], Vh[:keep]
-    B = Vh.conj().T @ ((U.conj().T @ H) / S[:, None].to(H.dtype))
-    R = H - Phi @ B
-    return Phi, U, S, Vh, B, R
+    UhH = U.conj().T @ H
+    B = Vh.conj().T @ (UhH / S[:, None].to(H.dtype))
+    R = H - U @ UhH
+    Ginv = Vh.conj().T @ (Vh / (S[:, None].to(H.dtype) ** 2))
+    return Phi, U, Ginv, B, R
 
 
 def optdmd(H: torch.Tensor, t: torch.Tensor, r: int, alpha0: torch.Tensor | None = None,
-           maxiter: int = 30, tol: float = 1e-6, eps_stall: float = 1e-12, init_lambda: float = 1.0,
+           maxiter: int = 30, tol: float = 1e-6, eps_stall: float | None = None, init_lambda: float = 1.0,
            lamup: float = 2.0, maxlam: int = 52) -> OptDMDResult:
     """Optimized DMD of the rows of H (snapshots at times t) with r exponentials.
 
     Defaults (maxiter 30, tol 1e-6, eps_stall 1e-12, lambda 1, x2 up to 52 times) are the ones
-    commonly used for this algorithm; tol is on the relative residual ||R||_F / ||H||_F."""
+    commonly used for this algorithm; tol is on the relative residual ||R||_F / ||H||_F.
+    ``eps_stall`` (relative gain below which the iteration counts as stalled): None = 1e-12 in
+    complex128 and 1e-6 in complex64 -- there the residual norm itself carries ~1e-7 of rounding,
+    and a tighter test makes every late iteration walk lambda through all its 52 doublings (one
+    projection each) before it gives up: measured 59 instead of 9 ms per iteration at cfg5."""
     cdtype = torch.complex128 if H.dtype in (torch.float64, torch.complex128) else torch.complex64
     rdtype = torch.float64 if cdtype == torch.complex128 else torch.float32
+    if eps_stall is None:
+        eps_stall = 1e-12 if cdtype == torch.complex128 else 1e-6
     H = H.to(cdtype)
     t = (t.real if t.is_complex() else t).to(device=H.device, dtype=torch.float64)
     # the parameters stay complex128 whatever the working dtype of the n x r matrices is
@@ -148,18 +189,18 @@ def optdmd(H: torch.Tensor, t: torch.Tensor, r: int, alpha0: torch.Tensor | None
     pieces = _project(alpha, t, H)
     if pieces is None:
         raise ValueError("optdmd: exp(alpha0 * t) is not finite in the working dtype")
-    Phi, U, S, Vh, B, R = pieces
+    Phi, U, Ginv, B, R = pieces
     err = float(torch.linalg.norm(R) / normH)
     n_iter, converged = 0, err < tol
     errs = [err]
+    n_proj = 1
     while n_iter < maxiter and not converged:
         n_iter += 1
         W = tw[:, None] * Phi
         PW = W - U @ (U.conj().T @ W)
         C = W.conj().T @ R                                           # (r, n_s)
         A1 = (PW.conj().T @ PW) * (B.conj() @ B.T)
-        Sinv2V = Vh / (S[:, None].to(cdtype) ** 2)                    # S^-2 Vh
-        A2 = (Vh.conj().T @ Sinv2V) * (C.conj() @ C.T)
+        A2 = Ginv * (C.conj() @ C.T)                                  # (Phi^H Phi)^-1 = V S^-2 V^H
         JtJ = (A1 + A2).to(torch.complex128)
         g = (C * B.conj()).sum(dim=1).to(torch.complex128)
         dg = torch.diagonal(JtJ).real.clamp_min(1e-300).to(torch.complex128)
@@ -169,9 +210,11 @@ def optdmd(H: torch.Tensor, t: torch.Tensor, r: int, alpha0: torch.Tensor | None
             delta = torch.linalg.solve(M, g)
             a_new = alpha + delta
             pieces = _project(a_new, t, H)
-            if pieces is None or not bool(torch.isfinite(pieces[5].real).all()):
+            nonlocal n_proj
+            n_proj += 1
+            if pieces is None or not bool(torch.isfinite(pieces[4].real).all()):
                 return a_new, None, math.inf
-            return a_new, pieces, float(torch.linalg.norm(pieces[5]) / normH)
+            return a_new, pieces, float(torch.linalg.norm(pieces[4]) / normH)
 
         a_new, pieces, e_new = trial(lam)
         if e_new < err:
@@ -187,7 +230,7 @@ def optdmd(H: torch.Tensor, t: torch.Tensor, r: int, alpha0: torch.Tensor | None
             if not improved:
                 break                                               # stalled: keep the current alpha
         gain = err - e_new
-        alpha, (Phi, U, S, Vh, B, R), err = a_new, pieces, e_new
+        alpha, (Phi, U, Ginv, B, R), err = a_new, pieces, e_new
         errs.append(err)
         if err < tol:
             converged = True
@@ -199,7 +242,7 @@ def optdmd(H: torch.Tensor, t: torch.Tensor, r: int, alpha0: torch.Tensor | None
     order = torch.argsort(-amp)
     return OptDMDResult(eigs=alpha[order], modes=modes[:, order], amplitudes=amp[order].to(rdtype),
                         rel_error=err, n_iter=n_iter, converged=converged,
-                        info={"errors": errs, "lambda": lam})
+                        info={"errors": errs, "lambda": lam, "projections": n_proj})
 
 
 def _match(reference: torch.Tensor, values: torch.Tensor) -> torch.Tensor:
@@ -236,7 +279,7 @@ def bopdmd(H: torch.Tensor, t: torch.Tensor, r: int, num_trials: int = 0, trial_
     mean = A.mean(dim=0)
     std = torch.sqrt(((A - mean).abs() ** 2).mean(dim=0))
     cdtype = mean.dtype
-    _, _, _, _, B, R = _project(mean.to(torch.complex128), t.to(H.device), H.to(cdtype))
+    _, _, _, B, R = _project(mean.to(torch.complex128), t.to(H.device), H.to(cdtype))
     amp = torch.linalg.norm(B, dim=1)
     modes = (B / amp[:, None].clamp_min(1e-300).to(cdtype)).T.contiguous()
     order = torch.argsort(-amp)

@@ -763,6 +763,7 @@ def svd_snapshots(Xt, n_components: int, delay: int = 1, oversample: int | None 
         ref = lam[1] if (mus is not None and lam.numel() > 1) else lam1   # the deflated scale
         steep = float(lam[min(k, lam.numel()) - 1]) < 1e-7 * float(ref)
         polish = steep and refine
+        tp0 = _sync_time(dev) if (timings and polish) else 0.0
         if polish:
             # Steep spectrum (s_k < 3e-4 s_1): G (sums of fp32 products) resolves eigenvalues down
             # to ~1e-9 lambda_1 only, so the trailing wanted directions are poorly determined by
@@ -788,6 +789,8 @@ def svd_snapshots(Xt, n_components: int, delay: int = 1, oversample: int | None 
             comm.broadcast_(V)
             lam = torch.ones_like(lam)                                # no S^-1 scaling of E V below
             info["polished"] = True
+            if timings:
+                info["t_polish"] = _sync_time(dev) - tp0              # (part of t_eig: two passes over X)
         elif steep:
             info["warning"] = ("s_k < 3e-4 s_1 and refine=False: the Gram matrix of fp32 products resolves "
                                "eigenvalues down to ~1e-9 lambda_1 only")

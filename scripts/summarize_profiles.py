@@ -70,6 +70,15 @@ def main():
                 w = csv.DictWriter(g, fieldnames=list(rr[0].keys()))
                 w.writeheader()
                 w.writerows(rr[:20])
+    fp = find(os.path.join(raw, "stats_powerlaw"), "kernel_stats.csv")
+    if fp:   # the same step on the gap-free spectrum: what the eigen stage launches
+        rp = list(csv.DictReader(open(fp)))
+        rp.sort(key=lambda r: -float(r.get("TotalDurationNs", 0) or 0))
+        if rp:
+            with open(os.path.join(out, f"{tag}_bench_powerlaw_kernel_stats.csv"), "w", newline="") as g:
+                w = csv.DictWriter(g, fieldnames=list(rp[0].keys()))
+                w.writeheader()
+                w.writerows(rp[:25])
     f, rows = kernel_stats(raw)
     rows.sort(key=lambda r: -float(r.get("TotalDurationNs", 0) or 0))
     top = rows[:12]

@@ -398,10 +398,10 @@ def _device_pipeline(ds: Dataset, parsed_config: dict, comm=None, kern=None, dev
     wide = rows_global < len(take) - d + 1
     shard = f" (rank {comm.rank} of {comm.world_size}: latitude rows {band[0]}:{band[1]})" if band else ""
     stream_bytes = int(os.environ.get("DMDX_STREAM_BYTES", "0"))      # > 0 forces the streaming path (tests)
-    # what can be streamed from the file in passes when X does not fit: the standard path on centred
-    # rows (its exact mean deflation would need further passes), the randomized path as it is
-    can_stream = (not wide and not parsed_config["save_data_matrix"]
-                  and (parsed_config["svd_type"] == "randomized" or center))
+    # what can be streamed from the file in passes when X does not fit: anything tall whose data
+    # matrix is not asked for (un-centred standard SVD included: the exact mean deflation centres
+    # the pieces as they pass; a spectrum steeper than the Gram resolves costs one more pass)
+    can_stream = not wide and not parsed_config["save_data_matrix"]
     if device.type == "cuda" and not stream_bytes:
         # X should be resident: find out before the allocator does
         rows = len(names) * nlev * ((band[1] - band[0]) if band else nlat) * nlon
@@ -423,16 +423,15 @@ def _device_pipeline(ds: Dataset, parsed_config: dict, comm=None, kern=None, dev
                     f"the snapshot matrix of this rank ({rows} x {len(take)} fp32 = {4 * rows * len(take) / 1e9:.1f} GB) "
                     f"does not fit the {free / 1e9:.1f} GB of free HBM; shard the space points over more GPUs: "
                     f"python -m torch.distributed.run --nproc-per-node N -m dmd_era5_amd.era5_svd with N >= "
-                    f"{max(ranks, comm.world_size + 1)} (without save_data_matrix -- and, for svd_type = standard, "
-                    "with mean_center -- such a slice is streamed from the file in passes instead)")
+                    f"{max(ranks, comm.world_size + 1)} (without save_data_matrix such a slice is streamed from the "
+                    "file in passes instead)")
 
     blocks = []
     if stream_bytes:
         # X does not fit: the Gram is accumulated and the projection made while latitude sub-bands of
-        # the variables pass through the HBM, twice (svd.svd_snapshots_streaming)
+        # the variables pass through the HBM, two or three times (svd.svd_snapshots_streaming)
         if not can_stream:
-            raise ValueError("the streaming path needs save_data_matrix = False, a tall problem and, for "
-                             "svd_type = standard, mean_center = True")
+            raise ValueError("the streaming path needs save_data_matrix = False and a tall problem")
         i0, i1 = band if band else (0, nlat)
         h = max(1, stream_bytes // max(1, 4 * len(take) * nlev * nlon))       # latitude rows per piece
         sub = [(j, min(i1, j + h)) for j in range(i0, i1, h)]

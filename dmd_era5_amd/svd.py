@@ -665,6 +665,44 @@ def _magnitude_guard(with_mean: bool):
     return deco
 
 
+def _eig_mean_deflated(G, w, musq, delay: int, l: int, eig_method: str, info: dict, kern):
+    """Top-l eigenpairs of E^T E = G + 1 w^T + w 1^T + d |mu|^2 1 1^T from the Gram G = A^T A of the
+    row-centred matrix, w = A^T mu~ and |mu|^2 (see :func:`svd_snapshots`): the dominant pair is
+    split off exactly (Schur complement of the direction q = 1 / sqrt(nd)), the rest comes from
+    the small-scale matrix Gd, and a Rayleigh-Ritz step in span{q, z, V_d} restores the coupling.
+    Returns (lam, V, lam_d, l)."""
+    nd, dev = G.shape[0], G.device
+    rootn = math.sqrt(nd)
+    q = torch.full((nd,), 1.0 / rootn, dtype=torch.float64, device=dev)
+    h = G @ q
+    qh = torch.dot(q, h)
+    alpha = qh + 2.0 * rootn * torch.dot(w, q) + delay * musq[0] * nd
+    zf = h + rootn * w
+    z = zf - q * torch.dot(q, zf)
+    Gd = G - torch.outer(q, h) - torch.outer(h, q) + qh * torch.outer(q, q) - torch.outer(z, z) / alpha
+    Gd = 0.5 * (Gd + Gd.T)
+    lam_d, Vd = top_eigh(Gd, max(1, l - 1), method=eig_method, info=info, kern=kern)
+    # Basis of the complement: z itself (G q = alpha q + z: with it the dominant pair is
+    # exact up to lambda_2 / alpha, whatever part of z lies outside the kept modes) and the
+    # leading eigenvectors of Gd, projected off q (a rank-deficient Gd returns arbitrary
+    # null vectors, q among them); the projected matrix comes from products, not from lam_d.
+    Bs = torch.cat([z[:, None] / torch.linalg.vector_norm(z).clamp_min(1e-300), Vd], dim=1)
+    Bs = _orth(Bs - torch.outer(q, q @ Bs))
+    c = Bs.T @ z
+    T11 = Bs.T @ (Gd @ Bs) + torch.outer(c, c) / alpha
+    T = torch.zeros((Bs.shape[1] + 1,) * 2, dtype=torch.float64, device=dev)
+    T[0, 0] = alpha
+    T[0, 1:] = c
+    T[1:, 0] = c
+    T[1:, 1:] = 0.5 * (T11 + T11.T)
+    lam, Z0 = _eigh_desc(T, kern)
+    l = min(l, lam.numel())
+    lam, Z0 = lam[:l].contiguous(), Z0[:, :l]
+    V = torch.cat([q[:, None], Bs], dim=1) @ Z0
+    info["mean_deflated"] = True
+    return lam, V, lam_d, l
+
+
 @_magnitude_guard(with_mean=True)
 def svd_snapshots(Xt, n_components: int, delay: int = 1, oversample: int | None = None,
                   refine: bool = True, flip_sign: bool = True, comm: Comm | None = None,
@@ -726,38 +764,11 @@ def svd_snapshots(Xt, n_components: int, delay: int = 1, oversample: int | None 
         k = min(n_components, nd, Mg)  # np.linalg.svd(full_matrices=False)[:k]
         p = oversample if oversample is not None else max(8, k // 4)
         l = min(nd, k + p) if refine else k
+        lam_d = None
         if mus is None:
             lam, V = top_eigh(G, l, method=eig_method, info=info, kern=kern)
         else:
-            rootn = math.sqrt(nd)
-            q = torch.full((nd,), 1.0 / rootn, dtype=torch.float64, device=dev)
-            h = G @ q
-            qh = torch.dot(q, h)
-            alpha = qh + 2.0 * rootn * torch.dot(w, q) + delay * musq[0] * nd
-            zf = h + rootn * w
-            z = zf - q * torch.dot(q, zf)
-            Gd = G - torch.outer(q, h) - torch.outer(h, q) + qh * torch.outer(q, q) - torch.outer(z, z) / alpha
-            Gd = 0.5 * (Gd + Gd.T)
-            lam_d, Vd = top_eigh(Gd, max(1, l - 1), method=eig_method, info=info, kern=kern)
-            # Basis of the complement: z itself (G q = alpha q + z: with it the dominant pair is
-            # exact up to lambda_2 / alpha, whatever part of z lies outside the kept modes) and the
-            # leading eigenvectors of Gd, projected off q (a rank-deficient Gd returns arbitrary
-            # null vectors, q among them); the projected matrix comes from products, not from lam_d.
-            Bs = torch.cat([z[:, None] / torch.linalg.vector_norm(z).clamp_min(1e-300), Vd], dim=1)
-            Bs = _orth(Bs - torch.outer(q, q @ Bs))
-            c = Bs.T @ z
-            T11 = Bs.T @ (Gd @ Bs) + torch.outer(c, c) / alpha
-            T = torch.zeros((Bs.shape[1] + 1,) * 2, dtype=torch.float64, device=dev)
-            T[0, 0] = alpha
-            T[0, 1:] = c
-            T[1:, 0] = c
-            T[1:, 1:] = 0.5 * (T11 + T11.T)
-            Vd = Bs
-            lam, Z0 = _eigh_desc(T, kern)
-            l = min(l, lam.numel())
-            lam, Z0 = lam[:l].contiguous(), Z0[:, :l]
-            V = torch.cat([q[:, None], Vd], dim=1) @ Z0
-            info["mean_deflated"] = True
+            lam, V, lam_d, l = _eig_mean_deflated(G, w, musq, delay, l, eig_method, info, kern)
         comm.broadcast_(lam, V)
         lam1 = lam[0].clamp_min(1e-300)
         ref = lam[1] if (mus is not None and lam.numel() > 1) else lam1   # the deflated scale
@@ -854,55 +865,141 @@ def svd_snapshots(Xt, n_components: int, delay: int = 1, oversample: int | None 
 # ---------------------------------------------------------------------------
 def svd_snapshots_streaming(pieces, n_components: int, rows_global: int, delay: int = 1,
                             oversample: int | None = None, flip_sign: bool = True,
-                            comm: Comm | None = None, kern=None) -> tuple:
-    """Method of snapshots for an X that does not fit the HBM: ``pieces()`` is called twice and
-    yields, piece after piece, lists of (n, mb) row blocks (centred / scaled already, resident
-    only until the next piece is asked for).  Pass 1 accumulates the Gram, pass 2 projects:
-    only the m x l basis U' stays resident (l = k + max(8, k/4) columns against X's n).
+                            comm: Comm | None = None, kern=None, deflate_mean: bool | None = None) -> tuple:
+    """Method of snapshots for an X that does not fit the HBM: ``pieces()`` is called once per pass
+    and yields, piece after piece, lists of (n, mb) row blocks (pre-processed as the configuration
+    asks; resident only until the next piece is asked for, so they may be modified in place).
+    Pass 1 accumulates the Gram, the last pass projects: only the m x l basis U' stays resident
+    (l = k + max(8, k/4) columns against X's n).
 
     Same arithmetic as :func:`svd_snapshots` on the concatenation of all pieces -- Gram in fp64
     across blocks, top-l eigenpairs, U' = E V S^-1, Rayleigh-Ritz refinement, sign convention --
-    without the two refinements that need further passes over X: the exact deflation of a dominant
-    time mean (the caller centres the rows) and the polish step for spectra steeper than the Gram
-    resolves (``info["warning"]`` says so when it would have run).
+    including its two refinements, each at the price of what it needs here:
+    * a dominant per-row time mean (un-centred data; ``deflate_mean`` None = detected on the first
+      piece of every rank, one exchange) is deflated exactly: the pieces are row-centred in place
+      as they pass (K5 in pass 1, which also yields w = A^T mu and |mu|^2 with one extra
+      single-column product per piece; the stored means -- 4 bytes per space point -- are
+      subtracted again in the later passes), no extra pass;
+    * a spectrum steeper than the Gram resolves (lambda_k < 1e-7 lambda_1) gets the polish step
+      V <- orth(E^T (E V)) as ONE extra pass (both products while a piece is resident).
     ``rows_global``: rows of the embedded matrix over all ranks (caps k like numpy's slicing).
     Returns (Ublocks, s, Vh, info): ``Ublocks[i]`` = list of (k, d*mb) tensors of piece i."""
     kern = _kern(kern)
     comm = comm or Comm()
-    info: dict = {"streaming": True}
+    info: dict = {"streaming": True, "passes_over_X": 2}
     G = None
-    for blocks in pieces():
-        G = kern.syrk_blocks(list(blocks), out=G) if (G is not None or len(blocks) > 1) else kern.syrk(blocks[0])
+    mus: list | None = None          # per block, in the order the pieces yield them
+    w = None
+    musq = None
+    for pi, blocks in enumerate(pieces()):
+        blocks = list(blocks)
+        if pi == 0:
+            if deflate_mean is None:
+                st = _shard_stats(blocks, comm, delay, True)
+                deflate_mean = blocks[0].shape[0] - delay + 1 > 2 and st["mean2"] > 100.0 * st["var"]
+            if deflate_mean:
+                mus = []
+        if mus is not None:
+            mp = [kern.row_center_scale_(B, False)[0] for B in blocks]
+            wp = _gemm_tn_blocks([mu[None, :].contiguous() for mu in mp], blocks, kern, Comm()).reshape(-1)
+            w = wp if w is None else w + wp
+            sq = torch.stack([(mu.double() ** 2).sum() for mu in mp]).sum().reshape(1)
+            musq = sq if musq is None else musq + sq
+            mus.extend(mp)
+        G = kern.syrk_blocks(blocks, out=G) if (G is not None or len(blocks) > 1) else kern.syrk(blocks[0])
     if G is None:
         raise ValueError("svd_snapshots_streaming: no pieces")
-    comm.allreduce_sum_(G)
+    n_t = G.shape[0]
+    if comm.world_size > 1 and n_t >= 64 and hasattr(kern, "pack_triu"):
+        G = kern.unpack_triu(comm.allreduce_sum_(kern.pack_triu(G)), n_t, out=G)
+    else:
+        comm.allreduce_sum_(G)
+    if mus is not None:
+        comm.allreduce_sum_(w)
+        comm.allreduce_sum_(musq)
     if not bool(torch.isfinite(torch.diagonal(G)).all()):
         raise np.linalg.LinAlgError("SVD did not converge")
     if delay > 1:
         G = kern.delay_shift_sum(G, delay)
+        if mus is not None:
+            ndw = w.numel() - delay + 1
+            w = torch.stack([w[kd:kd + ndw] for kd in range(delay)]).sum(dim=0)
     nd = G.shape[0]
+    dev = G.device
     k = min(n_components, nd, rows_global)
     p = oversample if oversample is not None else max(8, k // 4)
     l = min(nd, k + p)
-    lam, V = top_eigh(G, l, info=info, kern=kern)
+    lam_d = None
+    if mus is None:
+        lam, V = top_eigh(G, l, info=info, kern=kern)
+    else:
+        lam, V, lam_d, l = _eig_mean_deflated(G, w, musq, delay, l, "auto", info, kern)
     comm.broadcast_(lam, V)
     lam1 = lam[0].clamp_min(1e-300)
-    if float(lam[min(k, lam.numel()) - 1]) < 1e-7 * float(lam1):
-        info["warning"] = ("s_k < 3e-4 s_1: the Gram matrix of fp32 products resolves eigenvalues down to "
-                           "~1e-9 lambda_1 only, and the streaming path has no polish pass over X")
+    ref = lam[1] if (mus is not None and lam.numel() > 1) else lam1
+
+    def centred(blocks, off):
+        """The piece as pass 1 saw it: the stored row means subtracted again (in place)."""
+        blocks = list(blocks)
+        if mus is not None:
+            for j, B in enumerate(blocks):
+                B -= mus[off + j]
+        return blocks
+
+    polish = float(lam[min(k, lam.numel()) - 1]) < 1e-7 * float(ref)
+    if polish:
+        # one subspace iteration on X itself (see svd_snapshots): Z = E^T (E V), piece by piece
+        Vt32 = _pitched(kern, V.T.contiguous().to(torch.float32))
+        ones_v = V.sum(dim=0).to(torch.float32)
+        Zt, my, off = None, torch.zeros(V.shape[1], dtype=torch.float64, device=dev), 0
+        for blocks in pieces():
+            blocks = centred(blocks, off)
+            Eb = [embed_view(B, delay) for B in blocks]
+            Yb = [kern.skinny(E, Vt32) for E in Eb]
+            if mus is not None:
+                for j, Y in enumerate(Yb):
+                    mu = mus[off + j]
+                    Y.addmm_(ones_v[:, None], mu.repeat(delay)[None, :])
+                    my += Y.double() @ mu.double().repeat(delay)
+            Zt = kern.gemm_tn_blocks(Eb, Yb, out=Zt) if (Zt is not None or len(Eb) > 1) else kern.gemm_tn(Eb[0], Yb[0])
+            off += len(blocks)
+            del Yb
+        comm.allreduce_sum_(Zt)
+        if mus is not None:
+            comm.allreduce_sum_(my)
+            Zt = Zt + my[:, None]
+        Zn = Zt / torch.linalg.vector_norm(Zt, dim=1, keepdim=True).clamp_min(1e-300)
+        V = _orth(Zn.T.contiguous())
+        comm.broadcast_(V)
+        lam = torch.ones_like(lam)
+        info["polished"] = True
+        info["passes_over_X"] = 3
     good = lam > lam1 * 1e-14
+    if polish:
+        good = torch.ones_like(lam, dtype=torch.bool)
+    elif mus is not None:
+        good = lam > torch.maximum(lam_d[0].abs() * 1e-13, lam1 * 1e-15)
     s0 = torch.sqrt(torch.where(good, lam, torch.ones_like(lam)))
     inv_s0 = torch.where(good, 1.0 / s0, torch.zeros_like(s0))
     s0 = torch.where(good, s0, torch.zeros_like(s0))
     Wt = _pitched(kern, (V * inv_s0).T.contiguous().to(torch.float32))
-    Up = [[kern.skinny(embed_view(B, delay), Wt) for B in blocks] for blocks in pieces()]   # U' = E V S^-1
+    cvec = (V.sum(dim=0) * inv_s0).to(torch.float32)
+    Up, off = [], 0
+    for blocks in pieces():                                   # U' = E V S^-1
+        blocks = centred(blocks, off)
+        piece = [kern.skinny(embed_view(B, delay), Wt) for B in blocks]
+        if mus is not None:
+            for j, U in enumerate(piece):
+                U.addmm_(cvec[:, None], mus[off + j].repeat(delay)[None, :])
+        Up.append(piece)
+        off += len(blocks)
     flat = [U for piece in Up for U in piece]
     Mm = _gram_blocks(flat, kern, comm)
     mu_, Z = _graded_eigh(s0, Mm, kern)
     mu_, Z = mu_[:k].contiguous(), Z[:, :k].contiguous()
     comm.broadcast_(mu_, Z)
     s = torch.sqrt(mu_.clamp_min(0.0))
-    ok = s > s0[0] * 1e-7
+    ok = s > s0[0] * 1e-7 if (mus is None and not polish) else s > s[0] * 1e-7
     inv_s = torch.where(ok, 1.0 / torch.where(ok, s, torch.ones_like(s)), torch.zeros_like(s))
     Rt = _pitched(kern, ((s0[:, None] * Z) * inv_s[None, :]).T.contiguous().to(torch.float32))
     Ub = []

@@ -349,12 +349,14 @@ def test_main_on_a_wide_problem(svd_base_config, project_root, svd_type):
     assert np.all(U[np.abs(U).argmax(axis=0), np.arange(3)] > 0)              # u-based sign convention
 
 
-@pytest.mark.parametrize("svd_type,d,scale", [("standard", 1, False), ("standard", 2, True), ("randomized", 2, False)])
-def test_main_streams_a_slice_that_does_not_fit(svd_base_config, tmp_path, monkeypatch, svd_type, d, scale):
+@pytest.mark.parametrize("svd_type,d,scale,center", [("standard", 1, False, True), ("standard", 2, True, True),
+                                                     ("randomized", 2, False, True), ("standard", 2, False, False)])
+def test_main_streams_a_slice_that_does_not_fit(svd_base_config, tmp_path, monkeypatch, svd_type, d, scale, center):
     """A snapshot matrix larger than the free HBM is streamed from the file in passes instead of
-    being refused (standard with mean_center: Gram pass + projection pass; randomized: one pass
-    per power iteration + two).  Forced by a piece budget of 5 latitude rows; the result must equal
-    the resident run on the same slice."""
+    being refused (standard: Gram pass + projection pass; randomized: one pass per power iteration
+    + two).  Forced by a piece budget of 5 latitude rows; the result must equal the resident run on
+    the same slice.  ``center = False``: un-centred fields lifted by 5000 (s_1 ~ 1e3 s_2): the
+    streamed standard path deflates the time mean exactly, piece by piece, as the resident one."""
     from dmd_era5_amd import io_netcdf
     from dmd_era5_amd.config_parser import config_parser
     from dmd_era5_amd.create_mock_data import add_download_attributes, create_mock_era5
@@ -362,7 +364,7 @@ def test_main_streams_a_slice_that_does_not_fit(svd_base_config, tmp_path, monke
 
     cfg = dict(svd_base_config, start_datetime="2019-01-01T00", end_datetime="2019-01-04T00",
                variables="temperature,u_component_of_wind", levels="1000,500", svd_type=svd_type,
-               mean_center=True, scale=scale, delay_embedding=d, n_components=3, save_data_matrix=False, svd_seed=0)
+               mean_center=center, scale=scale, delay_embedding=d, n_components=3, save_data_matrix=False, svd_seed=0)
     out = {}
     for tag in ("resident", "streamed"):
         root = tmp_path / tag
@@ -378,7 +380,7 @@ def test_main_streams_a_slice_that_does_not_fit(svd_base_config, tmp_path, monke
             f = ds[name].values.astype(np.float64)
             f = f + 60 * np.sin(2 * np.pi * t / 24) * np.cos(lat) * np.cos(lon + v) + 35 * np.cos(2 * np.pi * t / 11) * np.sin(2 * lat) * np.sin(2 * lon)
             f = f + 20 * (t / len(t)) ** 2 * np.cos(3 * lon) * np.ones_like(lat)
-            ds[name].values = f.astype(np.float32)
+            ds[name].values = (f + (0.0 if center else 5000.0)).astype(np.float32)
         io_netcdf.to_netcdf(add_download_attributes(ds, p), p["era5_slice_path"])
         if tag == "streamed":
             monkeypatch.setenv("DMDX_STREAM_BYTES", str(5 * 4 * 73 * 2 * 72))
@@ -389,10 +391,12 @@ def test_main_streams_a_slice_that_does_not_fit(svd_base_config, tmp_path, monke
     assert np.allclose(b["s"].values, a["s"].values, rtol=1e-6 if svd_type == "standard" else 1e-5)
     assert np.abs(b["U"].values - a["U"].values).max() < 1e-4 * np.abs(a["U"].values).max()
     assert np.abs(b["V"].values - a["V"].values).max() < 1e-5
-    if d > 1:
+    if d > 1 and center:
         assert np.array_equal(b["X_mean"].values, a["X_mean"].values)
         if scale:
             assert np.allclose(b["X_std"].values, a["X_std"].values, rtol=1e-6)
+    if not center:
+        assert "X_mean" not in b.data_vars and float(b["s"].values[0]) > 200 * float(b["s"].values[1])
 
 
 @pytest.mark.parametrize("workload", ["small", "small-randomized"])

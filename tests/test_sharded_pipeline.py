@@ -135,7 +135,7 @@ def test_latitude_band_shards_assemble_to_the_single_rank_result(tmp_path, svd_t
     assert np.linalg.norm(rec - (U1 * s1) @ V1) <= 2e-4 * np.linalg.norm(rec)
 
 
-def _planted_slice(tmp_path):
+def _planted_slice(tmp_path, lift=0.0):
     from dmd_era5_amd import io_netcdf
     from dmd_era5_amd.create_mock_data import create_mock_era5
 
@@ -148,8 +148,8 @@ def _planted_slice(tmp_path):
         f = ds[name].values.astype(np.float64)
         f = f + 60 * np.sin(2 * np.pi * t / 24) * np.cos(lat) * np.cos(lon + v) + 35 * np.cos(2 * np.pi * t / 11) * np.sin(2 * lat) * np.sin(2 * lon)
         f = f + 20 * (t / 49.0) ** 2 * np.cos(3 * lon) * np.ones_like(lat)
-        ds[name].values = f.astype(np.float32)
-    path = str(tmp_path / "slice.nc")
+        ds[name].values = (f + lift).astype(np.float32)
+    path = str(tmp_path / ("slice.nc" if not lift else "lifted.nc"))
     os.environ["DMDX_NETCDF_BACKEND"] = "hdf5"
     io_netcdf.to_netcdf(ds, path)
     return path
@@ -197,3 +197,39 @@ def test_streaming_two_pass_pipeline_equals_the_resident_one(tmp_path, svd_type,
     for j in range(3):
         assert abs(np.dot(U[:, j], U1[:, j])) > 1 - 1e-6 and abs(np.dot(V[j], V1[j])) > 1 - 1e-6
     assert np.abs(U - U1).max() < 1e-4 * np.abs(U1).max()                # same rows in the same order, same signs
+
+
+@pytest.mark.parametrize("d,world", [(1, 1), (2, 1), (2, 2)])
+def test_streaming_uncentred_standard_svd_deflates_the_time_mean(tmp_path, d, world):
+    """mean_center = False on temperature-like fields (a 280 K mean under O(10) K anomalies) that do
+    not fit the HBM: the streamed standard path used to refuse this (the exact deflation of the
+    dominant time mean needs the row means); it now centres the pieces as they pass and must
+    agree with the resident pipeline -- whose mean-deflated route is itself pinned on numpy fp64
+    (tests/test_host_algorithms.py) -- to rounding, as one process and sharded over two ranks."""
+    from dmd_era5_amd import hdf5_lite
+    from dmd_era5_amd import svd as dsvd
+
+    if not hdf5_lite.available():
+        pytest.skip("libhdf5 not found")
+    path2 = _planted_slice(tmp_path, lift=5000.0)          # every variable lifted by a large constant: s_1 ~ 1e3 s_2
+    cfg = dict(_cfg("standard", d, False, False, None), save_data_matrix=False)
+    budget = 7 * 4 * 49 * 3 * 72
+    if world == 1:
+        U, s, V, coords, X, Xm, Xs = _run(path2, cfg, dsvd.Comm(), budget)
+    else:
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_worker, args=(r, world, port, path2, cfg, q, budget)) for r in range(world)]
+        for p in procs:
+            p.start()
+        got = [q.get(timeout=180) for _ in range(world)]
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        U, s, V, X, Xm, Xs, _ = next(g for g in got if g is not None)
+    U1, s1, V1, _, X1, Xm1, Xs1 = _run(path2, cfg, dsvd.Comm())
+    assert s[0] > 200 * s[1]                                   # the lifted mean dominates
+    assert np.allclose(s, s1, rtol=2e-6)
+    for j in range(3):
+        assert abs(np.dot(U[:, j], U1[:, j])) > 1 - 1e-6 and abs(np.dot(V[j], V1[j])) > 1 - 1e-6

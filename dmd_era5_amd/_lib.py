@@ -48,6 +48,8 @@ SIGNATURES = {
     "dmdx_svd_jacobi_f64": (C.c_int, [_p, _i64, _i64, _p, _p, _i64, _p, _p, _sz, _p]),
     "dmdx_symm_skinny_workspace_bytes": (_sz, [_i64, _i64]),
     "dmdx_symm_skinny_f64": (C.c_int, [_p, _i64, _i64, _p, _i64, _i64, C.c_double, _p, _i64, _p, _sz, _p]),
+    "dmdx_gemm_tn_f64_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "dmdx_gemm_tn_f64": (C.c_int, [_p, _i64, _p, _i64, _i64, _i64, _i64, _p, _i64, _p, _sz, _p]),
     "dmdx_pack_triu_f64": (C.c_int, [_p, _i64, _i64, _p, _p]),
     "dmdx_unpack_triu_f64": (C.c_int, [_p, _i64, _p, _i64, _p]),
     "dmdx_set_clock_probe": (C.c_int, [_p]),

@@ -19,6 +19,15 @@
 //     wave of workgroups; every split writes its own partial tile (no atomics: deterministic) and
 //     a second kernel sums the splits and subtracts shift * Q.
 //
+// K9  dmdx_gemm_tn_f64:  C = A^T B for tall fp64 blocks A (n x b1), B (n x b2), n ~ 10^4, b <= a few
+//     hundred: the Grams Q^T Q of the CholeskyQR rounds, the Rayleigh-Ritz matrices S^T (G S) and
+//     the block projections Q^T W of the eigen stage -- 18 launches per SVD on a gap-free spectrum,
+//     each ~250 us through rocBLAS (a 124 x 124 result from 8760 rows: 2.7e8 flops).  Same MFMA and
+//     the same even / odd 16-byte fragment loads as K8, both operands straight from global memory
+//     (a row of A and B is 1 KB and is re-read by the 2 x 2 waves of a workgroup from L1); 128 x 128
+//     output tiles, K split in chunks of 128 rows over gridDim.x, per-split partial tiles
+//     (deterministic) summed by a second kernel.
+//
 // pack / unpack of the upper triangle of a symmetric fp64 matrix: the Gram all-reduce of the
 //     row-sharded path moves n (n + 1) / 2 instead of n^2 doubles (307 instead of 614 MB at
 //     n = 8760).
@@ -171,6 +180,82 @@ int symm_plan(int64_t n, int64_t b, int* nsplit, int* kchunk) {
   return row_tiles;
 }
 
+// ---- K9: C = A^T B, tall fp64 operands ------------------------------------------------------
+constexpr int TN_KCH = 128;  // rows of A / B per workgroup
+
+struct Tn64Params {
+  const double* A;
+  const double* B;
+  double* P;  // [nsplit][b1][b2]
+  int64_t lda, ldb;
+  int n, b1, b2;
+};
+
+__global__ __launch_bounds__(256) void gemm_tn64_partial_kernel(Tn64Params p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int c1_0 = blockIdx.y * 128 + wr * 64, c2_0 = blockIdx.z * 128 + wc * 64;
+  const int kbeg = blockIdx.x * TN_KCH, kend = min(p.n, kbeg + TN_KCH);
+  if (c1_0 >= p.b1 || c2_0 >= p.b2) return;  // wave-uniform; no barriers in this kernel
+  int ca[2], cb[2];
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    ca[g] = min(c1_0 + 32 * g + 2 * r, p.b1 - 2);
+    cb[g] = min(c2_0 + 32 * g + 2 * r, p.b2 - 2);
+  }
+  f64x4 acc[2][2][2][2];  // [g][e][g'][f]
+#pragma unroll
+  for (int i = 0; i < 16; ++i) (&acc[0][0][0][0])[i] = f64x4{0.0, 0.0, 0.0, 0.0};
+  for (int k0 = kbeg; k0 < kend; k0 += 4) {
+    const int k = k0 + q;
+    const bool valid = k < kend;
+    const int64_t kk = valid ? k : kend - 1;
+    f64x2 a[2], b[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      a[g] = *reinterpret_cast<const f64x2*>(p.A + kk * p.lda + ca[g]);
+      b[g] = *reinterpret_cast<const f64x2*>(p.B + kk * p.ldb + cb[g]);
+      if (!valid) a[g] = f64x2{0.0, 0.0};
+    }
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int f = 0; f < 2; ++f)
+            acc[g][e][h][f] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[g][e], b[h][f], acc[g][e][h][f], 0, 0, 0);
+  }
+  double* Pt = p.P + (size_t)blockIdx.x * p.b1 * p.b2;
+#pragma unroll
+  for (int g = 0; g < 2; ++g)
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int c2 = c2_0 + 32 * h + 2 * r;
+        if (c2 >= p.b2) continue;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int c1 = c1_0 + 32 * g + 2 * (q + 4 * reg) + e;
+          if (c1 < p.b1)
+            *reinterpret_cast<f64x2*>(Pt + (size_t)c1 * p.b2 + c2) = f64x2{acc[g][e][h][0][reg], acc[g][e][h][1][reg]};
+        }
+      }
+}
+
+__global__ __launch_bounds__(256) void gemm_tn64_reduce_kernel(const double* __restrict__ P, int nsplit, int64_t nb,
+                                                               int b2, double* __restrict__ C, int64_t ldc) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= nb) return;
+  double s = 0.0;
+  for (int k = 0; k < nsplit; ++k) s += P[(int64_t)k * nb + idx];
+  const int64_t i = idx / b2;
+  C[i * ldc + (idx - i * b2)] = s;
+}
+
 // ---- upper triangle <-> packed, row by row: packed[i (2n - i + 1) / 2 + (j - i)] = A[i][j], j >= i
 __global__ __launch_bounds__(256) void pack_triu_kernel(const double* __restrict__ A, int64_t n, int64_t lda,
                                                         double* __restrict__ packed) {
@@ -253,6 +338,42 @@ extern "C" int dmdx_unpack_triu_f64(const double* packed, int64_t n, double* A, 
   DMDX_CHECK_ARG(n >= 1 && n <= 65535 && lda >= n, "unpack_triu: bad shape");
   hipLaunchKernelGGL(unpack_triu_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)n), dim3(256), 0,
                      (hipStream_t)stream, packed, n, lda, A);
+  DMDX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" size_t dmdx_gemm_tn_f64_workspace_bytes(int64_t n, int64_t b1, int64_t b2) {
+  if (n < 1 || b1 < 2 || b2 < 2) return 0;
+  const size_t ks = (size_t)((n + TN_KCH - 1) / TN_KCH);
+  return ks * (size_t)b1 * (size_t)b2 * sizeof(double);
+}
+
+extern "C" int dmdx_gemm_tn_f64(const double* A, int64_t lda, const double* B, int64_t ldb, int64_t n, int64_t b1,
+                                int64_t b2, double* Cm, int64_t ldc, void* workspace, size_t workspace_bytes,
+                                void* stream) {
+  DMDX_CHECK_ARG(A && B && Cm, "gemm_tn_f64: null pointer");
+  DMDX_CHECK_ARG(n >= 1 && n < (int64_t(1) << 30) && b1 >= 2 && b2 >= 2 && b1 <= 8192 && b2 <= 8192,
+                 "gemm_tn_f64: bad shape n=%lld b1=%lld b2=%lld", (long long)n, (long long)b1, (long long)b2);
+  DMDX_CHECK_ARG(b1 % 2 == 0 && b2 % 2 == 0 && lda % 2 == 0 && ldb % 2 == 0,
+                 "gemm_tn_f64: b1, b2, lda, ldb must be even (16-byte fragment loads)");
+  DMDX_CHECK_ARG(lda >= b1 && ldb >= b2 && ldc >= b2, "gemm_tn_f64: leading dimension too small");
+  DMDX_CHECK_ARG(dmdx_aligned16(A) && dmdx_aligned16(B) && dmdx_aligned16(workspace),
+                 "gemm_tn_f64: A, B and the workspace must be 16-byte aligned");
+  const size_t need = dmdx_gemm_tn_f64_workspace_bytes(n, b1, b2);
+  if (workspace == nullptr || workspace_bytes < need) {
+    dmdx_set_error("gemm_tn_f64: workspace %zu bytes < required %zu", workspace_bytes, need);
+    return DMDX_E_WORKSPACE;
+  }
+  const int ks = (int)((n + TN_KCH - 1) / TN_KCH);
+  DMDX_CHECK_ARG(ks <= 65535 * 32, "gemm_tn_f64: n too large");
+  hipStream_t st = (hipStream_t)stream;
+  Tn64Params p{A, B, reinterpret_cast<double*>(workspace), lda, ldb, (int)n, (int)b1, (int)b2};
+  const dim3 grid((unsigned)ks, (unsigned)((b1 + 127) / 128), (unsigned)((b2 + 127) / 128));
+  hipLaunchKernelGGL(gemm_tn64_partial_kernel, grid, dim3(256), 0, st, p);
+  DMDX_LAUNCH_CHECK();
+  const int64_t nb = b1 * b2;
+  hipLaunchKernelGGL(gemm_tn64_reduce_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, p.P, ks, nb, (int)b2,
+                     Cm, ldc);
   DMDX_LAUNCH_CHECK();
   return 0;
 }

@@ -45,6 +45,69 @@ def _flip_by_u(U: np.ndarray, V: np.ndarray):
     return U * sg[None, :], V * sg[:, None]
 
 
+# float64 input up to this many bytes is factored in fp64 (the reference's mock slices and test
+# inputs are float64: a few MB); anything larger is ERA5-sized and computed in fp32 like the
+# float32 slices the reference downloads
+FP64_MAX_BYTES = 2 << 30
+
+
+def _svd_fp64(X: np.ndarray, svd_type: str, n_components: int, device, random_state=None, omega=None,
+              n_oversamples: int = 10, n_iter="auto", **_ignored):
+    """The same two algorithms in fp64, for float64 input small enough to hold twice: the Gram
+    X^T X on the fp64 MFMA path (K9), the eigen stage of the fp32 engine (already fp64), the
+    projections through the library's fp64 GEMM.  Singular values agree with LAPACK's to
+    ~1e-16 s_1^2 / s_i (the Gram route squares the condition number -- in fp64 that leaves 1e-12
+    at s_i / s_1 = 1e-4), vectors to rounding; float64 in, float64 out, as the reference returns
+    for its float64 mock data (era5_svd.py:246-259)."""
+    from .kernels import default_kernels
+
+    kern = default_kernels()
+    dev = torch.device(device)
+    m, n = X.shape
+    wide = m < n
+    A = torch.from_numpy(np.ascontiguousarray(X.T if wide else X, dtype=np.float64)).to(dev)   # (rows, cols), tall
+    rows, cols = A.shape
+    k = min(n_components, cols)
+    if svd_type == "standard":
+        G = kern.gemm_tn64(A, A)
+        G = 0.5 * (G + G.T)
+        if not bool(torch.isfinite(torch.diagonal(G)).all()):
+            raise np.linalg.LinAlgError("SVD did not converge")
+        l = min(cols, k + max(8, k // 4))
+        lam, V = _svd.top_eigh(G, l, tol=1e-14, kern=kern)
+        good = lam > lam[0].clamp_min(1e-300) * 1e-28
+        s0 = torch.sqrt(torch.where(good, lam, torch.ones_like(lam)))
+        inv_s0 = torch.where(good, 1.0 / s0, torch.zeros_like(s0))
+        s0 = torch.where(good, s0, torch.zeros_like(s0))
+        Up = A @ (V * inv_s0)                                    # (rows, l) = X V S^-1
+        Mm = kern.gemm_tn64(Up, Up)
+        mu_, Z = _svd._graded_eigh(s0, 0.5 * (Mm + Mm.T), kern)
+        mu_, Z = mu_[:k], Z[:, :k]
+        s = torch.sqrt(mu_.clamp_min(0.0))
+        ok = s > s[0].clamp_min(1e-300) * 1e-14
+        inv_s = torch.where(ok, 1.0 / torch.where(ok, s, torch.ones_like(s)), torch.zeros_like(s))
+        U = Up @ ((s0[:, None] * Z) * inv_s[None, :])
+        Vh = (V @ Z).T
+    else:
+        l = min(cols, n_components + n_oversamples)
+        n_it = _svd.resolve_n_iter(n_components, rows, cols, n_iter)
+        if omega is None:
+            rs = random_state if isinstance(random_state, np.random.RandomState) else np.random.RandomState(random_state)
+            omega = rs.normal(size=(cols, n_components + n_oversamples))[:, :l]
+        Q = torch.as_tensor(np.asarray(omega, dtype=np.float64)).to(dev)
+        for _ in range(n_it):                                    # extmath.py:349-351, QR normaliser
+            Q, _ = torch.linalg.qr(A @ Q)
+            Q, _ = torch.linalg.qr(A.T @ Q)
+        Q, _ = torch.linalg.qr(A @ Q)                            # extmath.py:355
+        Uh, s, Vh = torch.linalg.svd(Q.T @ A, full_matrices=False)
+        U, s, Vh = (Q @ Uh)[:, :k], s[:k], Vh[:k]
+    U, s, Vh = U.cpu().numpy(), s.cpu().numpy(), Vh.cpu().numpy()
+    if wide:
+        U, Vh = np.ascontiguousarray(Vh.T), np.ascontiguousarray(U.T)
+    U, Vh = _flip_by_u(U, Vh)
+    return U, s, Vh
+
+
 def svd_numpy(X: np.ndarray, svd_type: str, n_components: int, device="cuda", **opts):
     """Rank-``n_components`` SVD of X (space x time) on the GPU.
 
@@ -55,6 +118,8 @@ def svd_numpy(X: np.ndarray, svd_type: str, n_components: int, device="cuda", **
     if svd_type not in SUPPORTED_SVD_TYPES:
         raise ValueError(f"SVD type {svd_type} is not supported.")
     out_dtype = X.dtype if X.dtype in (np.float32, np.float64) else np.float64
+    if X.dtype == np.float64 and X.nbytes <= FP64_MAX_BYTES and not opts.get("comm"):
+        return _svd_fp64(X, svd_type, n_components, device, **opts)
     m, n = X.shape
     wide = m < n
     if wide:

@@ -171,10 +171,13 @@ def svd_on_era5(da, parsed_config: dict):
         log_and_print(logger, "Performing randomized SVD...")
     else:
         raise ValueError(f"SVD type {svd_type} is not supported.")
-    if getattr(X, "dtype", None) == np.float64:
-        log_and_print(logger, "Input is float64: the engine computes in fp32 on the MFMA units (the reference's "
-                              "ERA5 slices are float32) and returns float64 arrays that carry ~1e-6 relative "
-                              "accuracy, not LAPACK's 1e-12.", level="warning")
+    from .engine import FP64_MAX_BYTES
+
+    if getattr(X, "dtype", None) == np.float64 and X.nbytes > FP64_MAX_BYTES:
+        log_and_print(logger, "Input is float64 and larger than the fp64 path takes: the engine computes it in "
+                              "fp32 on the MFMA units (the reference's ERA5 slices are float32) and returns "
+                              "float64 arrays that carry ~1e-6 relative accuracy, not LAPACK's 1e-12.",
+                      level="warning")
     U, s, V = svd_numpy(X, svd_type, n_components, **_engine_opts(parsed_config))
     if s.size and float(s[0]) > 0 and float(s[-1]) <= 1e-7 * float(s[0]):
         log_and_print(logger, "Singular values below 1e-7 s_1 are under the fp32 resolution of the data: their "
@@ -588,6 +591,48 @@ def _device_pipeline(ds: Dataset, parsed_config: dict, comm=None, kern=None, dev
     return U, s, V, coords, X, X_mean, X_std
 
 
+def _small_float64_slice(ds: Dataset, parsed_config: dict) -> bool:
+    """float64 variables whose embedded snapshot matrix is small enough for the fp64 engine path
+    (the reference's mock slices: a few MB).  Real ERA5 slices are float32 and go to the device
+    pipeline."""
+    from .engine import FP64_MAX_BYTES
+
+    names = list(ds.data_vars)
+    if not names or any(np.dtype(ds[v].dtype) != np.float64 for v in names):
+        return False
+    cells = sum(int(np.prod(ds[v].shape)) for v in names)
+    return 8 * cells * int(parsed_config["delay_embedding"]) <= FP64_MAX_BYTES
+
+
+def _host_pipeline_fp64(ds: Dataset, parsed_config: dict):
+    """The reference's own sequence (ref era5_svd.py:384-415) on the mirrored slice tools, for
+    small float64 slices: slice -> resample -> standardize -> flatten -> delay-embed on the host
+    in float64 (a few MB: not a device job), then ``svd_on_era5``, whose float64 input takes the
+    engine's fp64 path (K9 Gram, fp64 eigen stage) -- so that the reference's float64 mock data
+    come back with float64 accuracy (1e-12 against numpy), not fp32's 1e-6.  Returns what
+    ``_device_pipeline`` returns."""
+    from .slice_tools import (apply_delay_embedding, flatten_era5_variables, resample_era5_dataset,
+                              slice_era5_dataset, standardize_data)
+
+    d = parsed_config["delay_embedding"]
+    ds = slice_era5_dataset(ds, levels=parsed_config["levels"])
+    ds = resample_era5_dataset(ds, parsed_config["delta_time"])
+    ds_mean = ds_std = None
+    if parsed_config["mean_center"] and parsed_config["scale"]:
+        ds, ds_mean, ds_std = standardize_data(ds)
+    elif parsed_config["mean_center"]:
+        ds, ds_mean, ds_std = standardize_data(ds, scale=False)
+    da = apply_delay_embedding(flatten_era5_variables(ds), d)
+    row = {c: da.coords[c] for c in ("space", "original_variable", "delay") if c in da.coords}
+    da_mean = da_std = None
+    if ds_mean is not None and d > 1:                                  # (the reference's d == 1 quirk: no X_mean)
+        da_mean = DataArray(np.tile(flatten_era5_variables(ds_mean).values, d), ("space",), row)
+        if ds_std is not None:
+            da_std = DataArray(np.tile(flatten_era5_variables(ds_std).values, d), ("space",), row)
+    U, s, V = svd_on_era5(da, parsed_config)
+    return U, s, V, da.coords, (da if parsed_config["save_data_matrix"] else None), da_mean, da_std
+
+
 def _dist_comm():
     """The communicator of this process: single-rank unless it runs under
     ``python -m torch.distributed.run --nproc-per-node N -m dmd_era5_amd.era5_svd`` (one process
@@ -659,7 +704,10 @@ def main(config: dict | None = None, write_to_netcdf: bool = False, use_dvc: boo
         ds = ds[parsed_config["variables"]]
         # slice_era5_dataset(levels=...) and resample_era5_dataset(...) happen inside, as index
         # selections applied while the slice is streamed to the device
-        U, s, V, coords, X, X_mean, X_std = _device_pipeline(ds, parsed_config, comm)
+        if comm.world_size == 1 and _small_float64_slice(ds, parsed_config):
+            U, s, V, coords, X, X_mean, X_std = _host_pipeline_fp64(ds, parsed_config)
+        else:
+            U, s, V, coords, X, X_mean, X_std = _device_pipeline(ds, parsed_config, comm)
         svd_results = None
         if comm.rank == 0:
             svd_results = combine_svd_results(U, s, V, coords, X=X, X_mean=X_mean, X_std=X_std)

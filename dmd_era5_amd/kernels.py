@@ -367,6 +367,29 @@ class HipKernels:
         _lib.check(rc, "dmdx_symm_skinny_f64")
         return Y
 
+    # -- K9 -----------------------------------------------------------------
+    def gemm_tn64(self, A: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
+        """C = A^T B for tall fp64 device blocks A (n, b1), B (n, b2): the small Gram-type products
+        of the eigen stage (fp64 MFMA, one launch + a reduce).  Odd widths / unaligned views go
+        through the library GEMM."""
+        if A.dtype != torch.float64 or B.dtype != torch.float64 or A.dim() != 2 or B.dim() != 2 \
+                or A.shape[0] != B.shape[0] or not (A.is_cuda and B.is_cuda):
+            raise _lib.DmdxError("gemm_tn64: A (n, b1) and B (n, b2) must be fp64 device matrices")
+        n, b1 = A.shape
+        b2 = B.shape[1]
+        ok = (b1 >= 2 and b2 >= 2 and b1 % 2 == 0 and b2 % 2 == 0 and A.stride(1) == 1 and B.stride(1) == 1
+              and A.stride(0) % 2 == 0 and B.stride(0) % 2 == 0 and A.data_ptr() % 16 == 0 and B.data_ptr() % 16 == 0
+              and n >= 256)
+        if not ok:
+            return A.T @ B
+        Cm = torch.empty((b1, b2), dtype=torch.float64, device=A.device)
+        ws = self._workspace(A.device, self._lib.dmdx_gemm_tn_f64_workspace_bytes(n, b1, b2))
+        rc = self._timed("gemm_tn64", (n, b1, b2), lambda: self._lib.dmdx_gemm_tn_f64(
+            _ptr(A), A.stride(0), _ptr(B), B.stride(0), n, b1, b2, _ptr(Cm), b2, _ptr(ws), ws.numel(), self._stream()
+        ))
+        _lib.check(rc, "dmdx_gemm_tn_f64")
+        return Cm
+
     # -- packed upper triangle (the Gram all-reduce of the row-sharded path) -----
     def pack_triu(self, A: torch.Tensor) -> torch.Tensor:
         """Upper triangle of a square fp64 device matrix, row by row: n (n + 1) / 2 doubles."""

@@ -173,7 +173,14 @@ def embed_view(Xt: torch.Tensor, d: int) -> torch.Tensor:
 # ---------------------------------------------------------------------------
 # small dense pieces (fp64, torch)
 # ---------------------------------------------------------------------------
-def _orth(Y: torch.Tensor, rounds: int = 2, _shifted: bool = False) -> torch.Tensor:
+def _tn(kern, A: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
+    """A^T B for tall fp64 blocks: K9 (fp64 MFMA, ~20 us) when the provider has it, else the
+    library GEMM (~250 us at 8760 x 124: tall-skinny shapes are not rocBLAS's case)."""
+    f = getattr(kern, "gemm_tn64", None) if kern is not None else None
+    return f(A, B) if f is not None else A.T @ B
+
+
+def _orth(Y: torch.Tensor, rounds: int = 2, _shifted: bool = False, kern=None) -> torch.Tensor:
     """Orthonormal basis of the columns of a tall fp64 block.  CholeskyQR2 (two rounds of
     Gram -> Cholesky -> triangular solve: three small GEMM-type calls, ~1 ms at 8760 x 210)
     instead of Householder QR (rocSOLVER geqrf+orgqr: ~9 ms).  A block too ill-conditioned for
@@ -185,9 +192,13 @@ def _orth(Y: torch.Tensor, rounds: int = 2, _shifted: bool = False) -> torch.Ten
     of a polynomial filter (orthogonal to ~cond^2 eps), not an orthonormal basis."""
     Q = Y
     for it in range(rounds):
-        G = Q.T @ Q
+        G = _tn(kern, Q, Q)
         L, err = torch.linalg.cholesky_ex(G)
-        if int(err) != 0 or not torch.isfinite(L).all():
+        # the triangular solve is queued BEFORE the host looks at the factorisation's status (one
+        # read-back of one flag): the device works on while the host waits for it
+        failed = torch.logical_or(err != 0, ~torch.isfinite(torch.diagonal(L)).all())
+        Qn = torch.linalg.solve_triangular(L, Q.T, upper=False).T
+        if bool(failed):
             if it == 0 and not _shifted:
                 tr = torch.diagonal(G).sum()
                 eye = torch.eye(G.shape[0], dtype=G.dtype, device=G.device)
@@ -195,10 +206,10 @@ def _orth(Y: torch.Tensor, rounds: int = 2, _shifted: bool = False) -> torch.Ten
                     L, err = torch.linalg.cholesky_ex(G + (rel * tr) * eye)
                     if int(err) == 0 and bool(torch.isfinite(L).all()):
                         Qs = torch.linalg.solve_triangular(L, Q.T, upper=False).T
-                        return _orth(Qs, rounds=max(rounds, 2) + (1 if rel == 1e-8 else 0), _shifted=True)
+                        return _orth(Qs, rounds=max(rounds, 2) + (1 if rel == 1e-8 else 0), _shifted=True, kern=kern)
             Qh, _ = torch.linalg.qr(Y, mode="reduced")
             return Qh
-        Q = torch.linalg.solve_triangular(L, Q.T, upper=False).T
+        Q = Qn
     return Q.contiguous()
 
 
@@ -359,13 +370,13 @@ def top_eigh(G: torch.Tensor, l: int, method: str = "auto", tol: float = 1e-9,
             return k8(G, Qb, shift)
         return torch.addmm(Qb, G, Qb, beta=-shift) if shift != 0.0 else G @ Qb
 
-    Q = _orth(gq(Q))
+    Q = _orth(gq(Q), kern=kern)
     products = 1
 
     def ritz(S, GS):
         """Rayleigh-Ritz of G in span(S) (S orthonormal, GS = G S): Ritz values (descending), Ritz
         vectors Qn, G Qn, and the residual norms of all of them relative to theta_1."""
-        T = S.T @ GS
+        T = _tn(kern, S, GS)
         T = 0.5 * (T + T.T)
         th, Z = _eigh_desc(T, kern)
         Qn = S @ Z
@@ -394,7 +405,7 @@ def top_eigh(G: torch.Tensor, l: int, method: str = "auto", tol: float = 1e-9,
     # and each step gains ~3 digits) this reaches the tolerance after 3 products; otherwise its
     # Ritz vectors are the start of the filtered iteration.
     for it in range(2):
-        Q = _orth(gq(Q))
+        Q = _orth(gq(Q), kern=kern)
         Y = gq(Q)
         products += 2
         th, Q, GQ, resv = ritz(Q, Y)
@@ -415,8 +426,8 @@ def top_eigh(G: torch.Tensor, l: int, method: str = "auto", tol: float = 1e-9,
     if b2 > b:
         W = gq(torch.randn((n, b2 - b), dtype=torch.float64, generator=gen, device=G.device))
         for _ in range(2):
-            W = W - Q @ (Q.T @ W)
-        W = _orth(W)
+            W = W - Q @ _tn(kern, Q, W)
+        W = _orth(W, kern=kern)
         th, Q, GQ, resv = ritz(torch.cat([Q, W], dim=1), torch.cat([GQ, gq(W)], dim=1))
         products += 2
         b = b2
@@ -460,9 +471,9 @@ def top_eigh(G: torch.Tensor, l: int, method: str = "auto", tol: float = 1e-9,
             # rounds before the Rayleigh-Ritz step (an orthonormal basis)
             Q = gq(Q, r_i)
             if i == deg - 1:
-                Q = _orth(Q)
+                Q = _orth(Q, kern=kern)
             elif i % 2 == 1:
-                Q = _orth(Q, rounds=1)
+                Q = _orth(Q, rounds=1, kern=kern)
             else:
                 Q = Q / torch.linalg.vector_norm(Q, dim=0, keepdim=True).clamp_min(1e-300)
         Y = gq(Q)

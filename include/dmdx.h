@@ -161,6 +161,16 @@ int dmdx_symm_skinny_f64(const double* G, int64_t n, int64_t ldg, const double* 
                          int64_t b, double shift, double* Y, int64_t ldy,
                          void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- K9: C = A^T B for tall fp64 blocks, A n x b1 (lda), B n x b2 (ldb), C b1 x b2 (ldc), all
+ * row-major.  The Grams of the CholeskyQR rounds, the Rayleigh-Ritz matrices and the block
+ * projections of the top-eigenpair solver (the same part of np.linalg.svd, era5_svd.py:251, as K8).
+ * fp64 MFMA, K split over workgroups, per-split partial tiles in the workspace (deterministic).
+ * b1, b2, lda, ldb even; A, B, workspace 16-byte aligned. */
+size_t dmdx_gemm_tn_f64_workspace_bytes(int64_t n, int64_t b1, int64_t b2);
+int dmdx_gemm_tn_f64(const double* A, int64_t lda, const double* B, int64_t ldb, int64_t n,
+                     int64_t b1, int64_t b2, double* C, int64_t ldc,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- upper triangle of a symmetric fp64 matrix <-> packed row by row ---------------------
  * packed[i (2n - i + 1) / 2 + (j - i)] = A[i][j], j >= i: what the Gram all-reduce of the
  * row-sharded path moves (n (n + 1) / 2 doubles instead of n^2).  unpack writes both triangles. */

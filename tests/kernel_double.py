@@ -72,6 +72,9 @@ class CpuKernelDouble:
             return out
         return Y
 
+    def gemm_tn64(self, A, B):
+        return A.T @ B
+
     def pack_triu(self, A):
         i, j = torch.triu_indices(A.shape[0], A.shape[0])
         return A[i, j].contiguous()

@@ -633,6 +633,26 @@ def test_symm_skinny_odd_shapes_take_the_library_path(K):
         K.symm_skinny(G.float(), Q.float())
 
 
+@pytest.mark.parametrize("n,b1,b2", [(256, 2, 2), (300, 34, 78), (1000, 124, 124), (8760, 78, 78), (8760, 124, 46),
+                                     (5000, 312, 250), (777, 130, 2)])
+def test_gemm_tn64_matches_fp64_gemm(K, n, b1, b2):
+    """C = A^T B on the fp64 MFMA path (K9) against torch's fp64 GEMM: |dC| <= 1e-13 sum|a||b|;
+    widths that are not multiples of 32 / 128, several output tiles, a K tail (n % 128 != 0,
+    n % 4 != 0), and the symmetric use (A is B: the Gram of a CholeskyQR round)."""
+    g = torch.Generator(device="cuda").manual_seed(n + b1 * 7 + b2)
+    A = torch.randn((n, b1), generator=g, device="cuda", dtype=torch.float64)
+    B = torch.randn((n, b2), generator=g, device="cuda", dtype=torch.float64)
+    Cm = K.gemm_tn64(A, B)
+    ref = A.T @ B
+    bound = 1e-13 * (A.abs().T @ B.abs()) + 1e-300
+    assert Cm.shape == (b1, b2) and bool(((Cm - ref).abs() <= bound).all())
+    assert torch.equal(K.gemm_tn64(A, B), Cm)                                   # deterministic
+    G = K.gemm_tn64(A, A)
+    assert bool(((G - A.T @ A).abs() <= 1e-13 * (A.abs().T @ A.abs())).all())
+    # odd widths take the library path
+    assert torch.allclose(K.gemm_tn64(A[:, :b1 - 1].contiguous(), B), A[:, :b1 - 1].T @ B, rtol=1e-12, atol=1e-9)
+
+
 @pytest.mark.parametrize("n", [1, 2, 65, 300, 1031])
 def test_pack_unpack_triu_roundtrip(K, n):
     g = torch.Generator(device="cuda").manual_seed(n)

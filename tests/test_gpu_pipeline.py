@@ -95,7 +95,7 @@ def test_svd_on_era5_shapes_like_reference_test(svd_base_config, svd_type):
     U, s, V = svd_on_era5(da, p)
     n_samples, n_time = da.shape
     assert U.shape == (n_samples, 10) and s.shape == (10,) and V.shape == (10, n_time)
-    assert U.dtype == np.float64                     # fp64 in -> fp64 out (fp32 arithmetic)
+    assert U.dtype == np.float64                     # fp64 in -> fp64 out (fp64 arithmetic: engine._svd_fp64)
     assert np.all(np.diff(s) <= 1e-6 * s[0])
     Ur, sr, Vr = orc.svd_standard(da.values, 10)
     assert np.allclose(s[:1], sr[:1], rtol=1e-5)     # un-centred mock: one dominant component
@@ -440,3 +440,51 @@ def test_bench_two_ranks_on_one_gpu_over_gloo(workload):
     if workload == "small":
         assert out["roofline"]["bound"] == "mfma" and out["roofline"]["frac"] > 0
         assert "one packed-triangle Gram all-reduce" in out["config"]["sharding"]
+
+
+@pytest.mark.parametrize("svd_type,center,scale,d", [("standard", True, False, 2), ("standard", True, True, 1),
+                                                     ("standard", False, False, 2), ("randomized", True, False, 2)])
+def test_float64_mock_slice_comes_back_with_float64_accuracy(svd_base_config, project_root, svd_type, center, scale, d):
+    """BASELINE config 1 / the reference's own test inputs are float64 (create_mock_era5): such
+    slices take the fp64 path -- the reference's host sequence on the mirrored slice tools, the
+    Gram on the fp64 MFMA kernel (K9), the fp64 eigen stage -- and must agree with the reference's
+    arithmetic (oracle.preprocess + np.linalg.svd on float64) to float64 accuracy, through
+    main() and through svd_on_era5: 1e-11 on every singular value (round 1: 5e-6, fp32
+    arithmetic), vectors to 1e-9 where the gaps allow.  Randomized: against the oracle's
+    restatement of sklearn on the same Omega."""
+    from dmd_era5_amd.era5_svd import main, svd_on_era5
+
+    cfg = dict(svd_base_config, start_datetime="2019-01-01T00", end_datetime="2019-01-03T00",
+               variables="temperature,u_component_of_wind", levels="1000,850", svd_type=svd_type,
+               mean_center=center, scale=scale, delay_embedding=d, n_components=4, save_data_matrix=True, svd_seed=0)
+    p, ds = _write_slice(cfg, seed=3, dtype=np.float64)
+    # planted patterns so that the leading triplets are separated (the mock is white noise)
+    t = np.arange(ds["temperature"].shape[0], dtype=np.float64)[:, None, None, None]
+    lat = np.radians(ds.coords["latitude"].values)[None, None, :, None]
+    lon = np.radians(ds.coords["longitude"].values)[None, None, None, :]
+    from dmd_era5_amd import io_netcdf
+
+    for v, name in enumerate(ds.data_vars):
+        f = ds[name].values + 60 * np.sin(2 * np.pi * t / 24) * np.cos(lat) * np.cos(lon + v)
+        f = f + 35 * np.cos(2 * np.pi * t / 11) * np.sin(2 * lat) * np.sin(2 * lon) + 20 * (t / 49.0) ** 2 * np.cos(3 * lon)
+        ds[name].values = f
+    io_netcdf.to_netcdf(ds, p["era5_slice_path"])
+    res, _, _ = main(cfg, write_to_netcdf=False)
+    X, X_mean, X_std = orc.preprocess({k: ds[k].values for k in p["variables"]}, center, scale, d)
+    assert X.dtype == np.float64 and res["U"].values.dtype == np.float64 and res["X"].values.dtype == np.float64
+    assert np.array_equal(res["X"].values, X)                       # the host sequence IS the reference's arithmetic
+    if svd_type == "standard":
+        Uo, so, Vo = orc.svd_standard(X, 4)
+    else:
+        Uo, so, Vo = orc.svd_randomized(X, 4, random_state=0)
+    s, U, V = res["s"].values, res["U"].values, res["V"].values
+    assert np.abs(s / so - 1).max() < (1e-11 if svd_type == "standard" else 1e-9), np.abs(s / so - 1).max()
+    assert col_cosines(U[:, :3], Uo[:, :3]).min() > 1 - 1e-9 and col_cosines(V[:3].T, Vo[:3].T).min() > 1 - 1e-9
+    assert np.abs(U.T @ U - np.eye(4)).max() < 1e-12
+    if center and d > 1:
+        assert np.array_equal(res["X_mean"].values, X_mean)
+    # the function boundary the reference's own test calls (tests/test_03_era5_svd.py:164)
+    from dmd_era5_amd.labeled import DataArray
+
+    U2, s2, V2 = svd_on_era5(DataArray(X, ("space", "time")), p)
+    assert U2.dtype == np.float64 and np.abs(s2 / so - 1).max() < (1e-11 if svd_type == "standard" else 1e-9)

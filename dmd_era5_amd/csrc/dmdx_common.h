@@ -11,6 +11,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 void dmdx_set_error(const char* fmt, ...);
 
+// measurement aid (dmdx_set_clock_probe): 3 device uint64 the stamped kernels (K1 / K3 batch
+// launches, K2) add their core-clock cycles, reference ticks and workgroup count to; null = off
+extern unsigned long long* dmdx_clock_probe_ptr;
+
 #define DMDX_CHECK_ARG(cond, ...)        \
   do {                                   \
     if (!(cond)) {                       \

@@ -48,6 +48,8 @@
 
 #include "dmdx_common.h"
 
+unsigned long long* dmdx_clock_probe_ptr = nullptr;  // dmdx_set_clock_probe (measurement aid)
+
 namespace {
 
 constexpr int BT = 128;            // output tile edge
@@ -770,8 +772,6 @@ size_t batch_group_ws(const int64_t* K, int nb, int64_t nrow, int64_t ncol, int 
   return slabs * (size_t)pl.ntiles * pl.tm * BT * sizeof(double);
 }
 
-unsigned long long* g_clock_probe = nullptr;  // dmdx_set_clock_probe (measurement aid)
-
 int run_batch(const float* const* A, const int64_t* lda, const float* const* B, const int64_t* ldb,
               const int64_t* K, int nblocks, int64_t nrow, int64_t ncol, int syrk, double* D64, int64_t ld64,
               float* D32, int64_t ld32, int accumulate, void* ws, size_t ws_bytes, hipStream_t stream) {
@@ -813,7 +813,7 @@ int run_batch(const float* const* A, const int64_t* lda, const float* const* B, 
     bt.unit_begin[nb] = units;
     bt.slab_begin[nb] = slabs;
     bt.nblocks = nb;
-    bt.clk = g_clock_probe;
+    bt.clk = dmdx_clock_probe_ptr;
     p.nrow = (int)nrow;
     p.ncol = (int)ncol;
     p.ntr = pl.ntr; p.ntc = pl.ntc; p.ntiles = pl.ntiles; p.syrk = pl.syrk;
@@ -858,7 +858,7 @@ int dmdx_debug_read_stamps(unsigned long long* out8, int reset) {
 #endif
 
 int dmdx_set_clock_probe(unsigned long long* dev_counters3) {
-  g_clock_probe = dev_counters3;
+  dmdx_clock_probe_ptr = dev_counters3;
   return 0;
 }
 

@@ -34,7 +34,14 @@ constexpr int ROWS_PER_WG = 512;
 template <int C, bool ALIGNED>
 __global__ __launch_bounds__(256, 1) void skinny_kernel(
     const float* __restrict__ X, int64_t m, int64_t n, int64_t ldx, const float* __restrict__ W,
-    int64_t ldw, int l, float* __restrict__ Y, int64_t ldy) {
+    int64_t ldw, int l, float* __restrict__ Y, int64_t ldy, unsigned long long* clk) {
+  // measurement aid (dmdx_set_clock_probe; null on the product path): core-clock cycles and
+  // 100 MHz reference ticks of this workgroup's lifetime are added to clk[0..2] at the end
+  unsigned long long pc0 = 0, pr0 = 0;
+  if (clk != nullptr) {
+    pc0 = __builtin_amdgcn_s_memtime();
+    pr0 = __builtin_amdgcn_s_memrealtime();
+  }
   // W chunk image: [stage][column][32 k], unpadded; the 16-byte k-pieces of a column are stored
   // at piece index q ^ swz(column) so that the ds_read_b128 fragment reads below (32 columns x 2
   // pieces per wave) are bank-conflict free -- the layout of K1's operand panels
@@ -262,6 +269,14 @@ __global__ __launch_bounds__(256, 1) void skinny_kernel(
       }
     }
   }
+  if (clk != nullptr) {
+    const unsigned long long pc1 = __builtin_amdgcn_s_memtime(), pr1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) {
+      atomicAdd(&clk[0], pc1 - pc0);
+      atomicAdd(&clk[1], pr1 - pr0);
+      atomicAdd(&clk[2], 1ull);
+    }
+  }
 }
 
 template <int C>
@@ -273,10 +288,10 @@ int launch_skinny(const float* X, int64_t m, int64_t n, int64_t ldx, const float
   dim3 grid((unsigned)((m + ROWS_PER_WG - 1) / ROWS_PER_WG));
   if (aligned)
     hipLaunchKernelGGL((skinny_kernel<C, true>), grid, dim3(256), 0, stream, X, m, n, ldx, W, ldw, l,
-                       Y, ldy);
+                       Y, ldy, dmdx_clock_probe_ptr);
   else
     hipLaunchKernelGGL((skinny_kernel<C, false>), grid, dim3(256), 0, stream, X, m, n, ldx, W, ldw,
-                       l, Y, ldy);
+                       l, Y, ldy, dmdx_clock_probe_ptr);
   DMDX_LAUNCH_CHECK();
   return 0;
 }

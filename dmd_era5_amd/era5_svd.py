@@ -718,6 +718,9 @@ def main(config: dict | None = None, write_to_netcdf: bool = False, use_dvc: boo
         log_and_print(logger, msg, "error")
         raise Exception(msg) from e
     finally:
+        from .kernels import release_cached_workspaces
+
+        release_cached_workspaces()
         if created:
             import torch.distributed as dist
 

@@ -426,3 +426,9 @@ def default_kernels() -> HipKernels:
     if _default is None:
         _default = HipKernels()
     return _default
+
+
+def release_cached_workspaces() -> int:
+    """Free the partial-tile workspaces of the process-wide provider, if one exists (main() does
+    after every run: 10-19 GB at cfg2 / cfg3 that the next, possibly larger, slice may need)."""
+    return _default.release_workspace() if _default is not None else 0

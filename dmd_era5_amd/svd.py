@@ -306,6 +306,13 @@ def _filter_step_ms(n: int, b: int) -> float:
     return max(0.25, 1.0 * (n / 8760.0) ** 2) + 0.6 + 0.006 * b
 
 
+import os as _os
+
+# degree forecast x safety: one degree too many costs ~0.7 ms, one too few a whole extra pass + Rayleigh-Ritz
+# (~4 ms); measured on the power-law cfg2 Gram: 1.25 -> degrees [6, 2] 18.5 ms, 1.6 -> [7] 16.6 ms, 2.0 -> [8] 16.9 ms
+_CHEB_SAFETY = float(_os.environ.get("DMDX_CHEB_SAFETY", "1.75"))
+
+
 def top_eigh(G: torch.Tensor, l: int, method: str = "auto", tol: float = 1e-9,
              max_outer: int = 40, info: dict | None = None, kern=None):
     """Largest ``l`` eigenpairs of the symmetric PSD fp64 matrix ``G`` (n x n),
@@ -456,7 +463,7 @@ def top_eigh(G: torch.Tensor, l: int, method: str = "auto", tol: float = 1e-9,
                 info["eig_cheb_forecast_steps"] = float(min(need, 1e9))
             break
         # (the first forecast rests on the Ritz values of a freshly widened block: capped lower)
-        deg = int(min(max_deg if it else 10, max(2, math.ceil(1.25 * need) + 1)))
+        deg = int(min(max_deg if it else 10, max(2, math.ceil(_CHEB_SAFETY * need) + 1)))
         degrees.append(deg)
         roots = [0.5 * cut * (1.0 + math.cos(math.pi * (2 * i + 1) / (2 * deg))) for i in range(deg)]
         order = []

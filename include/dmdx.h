@@ -178,8 +178,9 @@ int dmdx_pack_triu_f64(const double* A, int64_t n, int64_t lda, double* packed, 
 int dmdx_unpack_triu_f64(const double* packed, int64_t n, double* A, int64_t lda, void* stream);
 
 /* ---- measurement aid (not on the path): sustained core clock of the Gram launches ----------
- * While dev_counters3 (3 device uint64, caller-zeroed) is set, every workgroup of
- * dmdx_syrk_blocks_f32 adds its core-clock cycles (s_memtime), its 100 MHz reference ticks
+ * While dev_counters3 (3 device uint64, caller-zeroed) is set, every workgroup of the batched
+ * launches (dmdx_syrk_blocks_f32, dmdx_gemm_tn_blocks_f32) and of dmdx_gemm_nn_skinny_f32 adds its
+ * core-clock cycles (s_memtime), its 100 MHz reference ticks
  * (s_memrealtime) and 1 to it: clock = 100 MHz * [0] / [1].  NULL (the default) switches the
  * stamps off again; bench.py's calibration block is the only caller. */
 int dmdx_set_clock_probe(unsigned long long* dev_counters3);

@@ -60,5 +60,40 @@ for name, label in (("skinny", "K2 skinny_kernel (Y = X Q)"), ("gemm_tn", "K3 ge
         "algorithmic_tflops": 2.0 * mb * n * l / (ms * 1e-3) / 1e12,
         "mfma_bound_note": "l is padded to 64 columns: at the nominal 157.3 TFLOP/s the padded MFMA work alone takes "
                            "%.2f ms per launch" % (2.0 * mb * n * 64 / 157.3e12 * 1e3)}
+# the core clock the chip holds under each of the two kernels (per-workgroup s_memtime /
+# s_memrealtime stamps, dmdx_set_clock_probe): both run the fp32 MFMA pipe while streaming X from
+# HBM, and the clock under that load is ~2.0 GHz, not the 2.4 GHz of the nominal peak
+lp = -(-l // 32) * 32
+Qt = torch.randn((l, n), device="cuda", dtype=torch.float32)
+Yb = [torch.randn((l, B.shape[1]), device="cuda", dtype=torch.float32) for B in blocks]
+
+
+def probed(fn):
+    ctr = torch.zeros(3, dtype=torch.int64, device="cuda")
+    fn()
+    torch.cuda.synchronize()
+    kern.clock_probe(ctr)
+    try:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        e1.synchronize()
+    finally:
+        kern.clock_probe(None)
+    cyc, ticks, wgs = (int(v) for v in ctr.tolist())
+    return 100.0 * cyc / max(ticks, 1), e0.elapsed_time(e1)
+
+
+for label, fn in (("K2 skinny_kernel (Y = X Q)", lambda: [kern.skinny(B, Qt) for B in blocks]),
+                  ("K3 gemm_tn_partial_kernel 64x128 tiles (Z = X^T Y)", lambda: kern.gemm_tn_blocks(blocks, Yb))):
+    if label not in out["kernels"]:
+        continue
+    mhz, ms_pass = probed(fn)
+    bound = 2.0 * m * n * lp / (157.3e12 * mhz / 2400.0) * 1e3
+    out["kernels"][label].update({
+        "core_clock_mhz": mhz, "ms_per_pass_over_X": ms_pass,
+        "padded_mfma_bound_ms_at_held_clock": bound, "frac_of_mfma_bound_at_held_clock": bound / ms_pass,
+        "hbm_bound_ms_at_6.3TBps": 4.0 * m * n / 6.3e12 * 1e3})
 out["s_head"] = [float(x) for x in res.s[:3].cpu()]
 print(json.dumps(out), flush=True)

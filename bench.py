@@ -487,6 +487,12 @@ def main():
                            "unit": "TFLOP/s", "frac": flops * args.steps / dt / 1e12 / PEAK_FP32_MFMA_TFLOPS,
                            "traffic": None, "flops_per_step": flops,
                            "note": "whole-step algorithmic rate (no per-launch events in the timed region)"}
+    if svd_type == "standard":
+        # stage split of one more step, outside the timed region (the stage timers synchronise)
+        st = dsvd.svd_snapshots(blocks, r, comm=comm, kern=kern, timings=True).info
+        out["stage_ms"] = {k[2:]: float(st[k]) * 1e3 for k in ("t_gram", "t_eig", "t_project", "t_refine", "t_total")}
+        if "t_polish" in st:
+            out["stage_ms"]["polish (inside eig)"] = float(st["t_polish"]) * 1e3
     out["kernel_ms_per_step"] = {k: float(np.sum(v)) / args.steps for k, v in by_name.items()}
     out["row_blocks"] = nblk
     out["svd_info"] = {k: (float(v) if isinstance(v, (int, float)) else v)

@@ -486,7 +486,8 @@ def main():
                            "achieved": flops * args.steps / dt / 1e12, "peak": PEAK_FP32_MFMA_TFLOPS,
                            "unit": "TFLOP/s", "frac": flops * args.steps / dt / 1e12 / PEAK_FP32_MFMA_TFLOPS,
                            "traffic": None, "flops_per_step": flops,
-                           "note": "whole-step algorithmic rate (no per-launch events in the timed region)"}
+                           "note": "whole-step algorithmic rate of ONE rank's shard (per GPU; no per-launch "
+                                   "events in the timed region)"}
     if svd_type == "standard":
         # stage split of one more step, outside the timed region (the stage timers synchronise)
         st = dsvd.svd_snapshots(blocks, r, comm=comm, kern=kern, timings=True).info

@@ -393,3 +393,26 @@ def test_streaming_standard_path_polishes_steep_spectra_in_one_extra_pass(d):
     assert float(cos.min()) > 1 - 1e-6
     if d == 1:
         assert np.abs(s.numpy() - ref).max() <= 2e-7 * ref[0]
+
+
+def test_explicit_normalizer_none_is_sklearns_arithmetic():
+    """`power_iteration_normalizer="none"` given explicitly is taken literally (sklearn's
+    un-normalised power iterations, extmath.py:314-316 / 349-351), unlike "auto", where the engine
+    keeps normalising also at n_iter <= 2.  On a gently decaying spectrum, where fp32 carries the
+    un-normalised iterate, both must agree with the oracle's restatement of sklearn run the same
+    way on the same Omega."""
+    rs = np.random.RandomState(11)
+    m, n, k = 3000, 80, 5
+    A, _ = np.linalg.qr(rs.standard_normal((m, n)))
+    B, _ = np.linalg.qr(rs.standard_normal((n, n)))
+    X = ((A * (1.0 / (1.0 + np.arange(n)))) @ B.T).astype(np.float32)
+    omega = np.random.RandomState(0).normal(size=(n, k + 5))
+    Uo, so, Vo = orc.svd_randomized(X.astype(np.float64), k, n_oversamples=5, n_iter=2,
+                                    power_iteration_normalizer="none", omega=omega)
+    r = dsvd.svd_randomized(_xt(X), k, n_oversamples=5, n_iter=2, power_iteration_normalizer="none",
+                            omega=omega, kern=K)
+    assert r.info["normalizer"] == "none"
+    assert np.allclose(r.s.numpy(), so, rtol=2e-5)
+    assert col_cosines(r.Ut.numpy().T, Uo).min() > 1 - 1e-6
+    ra = dsvd.svd_randomized(_xt(X), k, n_oversamples=5, n_iter=2, omega=omega, kern=K)   # "auto": normalised
+    assert np.allclose(ra.s.numpy(), so, rtol=2e-5)                      # same subspaces in exact arithmetic

@@ -27,6 +27,7 @@ n ~ 10^4 rows) runs in fp64 through torch on the same device.
 from __future__ import annotations
 
 import math
+import os
 import time
 from dataclasses import dataclass, field
 
@@ -306,11 +307,9 @@ def _filter_step_ms(n: int, b: int) -> float:
     return max(0.25, 1.0 * (n / 8760.0) ** 2) + 0.6 + 0.006 * b
 
 
-import os as _os
-
 # degree forecast x safety: one degree too many costs ~0.7 ms, one too few a whole extra pass + Rayleigh-Ritz
 # (~4 ms); measured on the power-law cfg2 Gram: 1.25 -> degrees [6, 2] 18.5 ms, 1.6 -> [7] 16.6 ms, 2.0 -> [8] 16.9 ms
-_CHEB_SAFETY = float(_os.environ.get("DMDX_CHEB_SAFETY", "1.75"))
+_CHEB_SAFETY = float(os.environ.get("DMDX_CHEB_SAFETY", "1.75"))
 
 
 def top_eigh(G: torch.Tensor, l: int, method: str = "auto", tol: float = 1e-9,

@@ -416,3 +416,24 @@ def test_explicit_normalizer_none_is_sklearns_arithmetic():
     assert col_cosines(r.Ut.numpy().T, Uo).min() > 1 - 1e-6
     ra = dsvd.svd_randomized(_xt(X), k, n_oversamples=5, n_iter=2, omega=omega, kern=K)   # "auto": normalised
     assert np.allclose(ra.s.numpy(), so, rtol=2e-5)                      # same subspaces in exact arithmetic
+
+
+def test_powerlaw_generator_has_the_spectrum_it_claims():
+    """bench.make_powerlaw_blocks (the hard-spectrum leg of bench.py and the gap-free GPU test):
+    singular values sigma_i sqrt(m) within the Marchenko-Pastur edge factors, every consecutive
+    ratio close to (i + 1) / i -- no gap anywhere -- and the same time factor for every shard."""
+    import bench
+
+    m, n = 6000, 48
+    blocks = bench.make_powerlaw_blocks(m, n, 7, torch.device("cpu"))
+    X = torch.cat(blocks, dim=1).numpy().T.astype(np.float64)           # (m, n)
+    s = np.linalg.svd(X, compute_uv=False)
+    expect = 100.0 / np.arange(1, n + 1) * np.sqrt(m)
+    assert np.all(np.abs(s / expect - 1) < 3.5 * np.sqrt(n / m))
+    assert np.all(s[:-1] / s[1:] < 2.2) and np.all(s[:-1] / s[1:] > 1.0)
+    other = bench.make_powerlaw_blocks(m, n, 7, torch.device("cpu"), shard=1)
+    Y = torch.cat(other, dim=1).numpy().T.astype(np.float64)
+    assert not np.allclose(X, Y)
+    # one global matrix: stacking the shards keeps the spectrum (x sqrt(2)), it does not double the rank
+    s2 = np.linalg.svd(np.concatenate([X, Y]), compute_uv=False)
+    assert np.all(np.abs(s2 / (expect * np.sqrt(2)) - 1) < 3.5 * np.sqrt(n / m))

@@ -31,10 +31,11 @@ constexpr int KB = 32;          // k rows per W chunk
 constexpr int ROWS_PER_WAVE = 128;
 constexpr int ROWS_PER_WG = 512;
 
-template <int C, bool ALIGNED>
+template <int C, bool ALIGNED, bool GRAM = false>
 __global__ __launch_bounds__(256, 1) void skinny_kernel(
     const float* __restrict__ X, int64_t m, int64_t n, int64_t ldx, const float* __restrict__ W,
-    int64_t ldw, int l, float* __restrict__ Y, int64_t ldy, unsigned long long* clk) {
+    int64_t ldw, int l, float* __restrict__ Y, int64_t ldy, unsigned long long* clk,
+    float* __restrict__ gpart) {
   // measurement aid (dmdx_set_clock_probe; null on the product path): core-clock cycles and
   // 100 MHz reference ticks of this workgroup's lifetime are added to clk[0..2] at the end
   unsigned long long pc0 = 0, pr0 = 0;
@@ -269,6 +270,46 @@ __global__ __launch_bounds__(256, 1) void skinny_kernel(
       }
     }
   }
+  // ---- fused Gram of the block just written (CholeskyQR of the range finder: G = Y^T Y would
+  // otherwise be another pass over the m x l matrix): the accumulators ARE the MFMA operands --
+  // lane (j, h) holds Y[row(e, r, h)][32 cc + j], which is A[i = j][k = h] of block cc as well as
+  // B[k = h][j] -- so 64 MFMAs per pair of column blocks contract the wave's 128 rows; the
+  // 32 x 32 fp32 partial of every (workgroup, wave, block pair) goes to its own slot (no atomics:
+  // deterministic) and a second kernel sums them in fp64.
+  if constexpr (GRAM) {
+    if (rowW + ROWS_PER_WAVE > m) {   // rows past the end hold clamped duplicates: not part of Y
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t row = rowW + 4 * ((r & 3) + 8 * (r >> 2) + 4 * lh) + e;
+          if (row >= m) {
+#pragma unroll
+            for (int cc = 0; cc < C; ++cc) acc[e][cc][r] = 0.f;
+          }
+        }
+    }
+    constexpr int NPAIR = C * (C + 1) / 2;
+    float* gp = gpart + ((size_t)blockIdx.x * 4 + wave) * (NPAIR * 1024);
+    int pair = 0;
+#pragma unroll
+    for (int c1 = 0; c1 < C; ++c1)
+#pragma unroll
+      for (int c2 = c1; c2 < C; ++c2) {
+        f32x16 d;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) d[q] = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            d = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[e][c1][r], acc[e][c2][r], d, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+          gp[pair * 1024 + ((q & 3) + 8 * (q >> 2) + 4 * lh) * 32 + l31] = d[q];
+        ++pair;
+      }
+  }
   if (clk != nullptr) {
     const unsigned long long pc1 = __builtin_amdgcn_s_memtime(), pr1 = __builtin_amdgcn_s_memrealtime();
     if (threadIdx.x == 0) {
@@ -279,20 +320,73 @@ __global__ __launch_bounds__(256, 1) void skinny_kernel(
   }
 }
 
+// sums the per-(workgroup, wave) 32 x 32 partials of every block pair in fp64 into G (l x l): one
+// workgroup per row of 32 output elements, 8 slot lanes x 32 elements; every thread sums its slots
+// s, s + 8, ... (coalesced 128-byte reads), the 8 lanes meet in LDS in a fixed order (deterministic)
+template <int C>
+__global__ __launch_bounds__(256) void skinny_gram_reduce_kernel(const float* __restrict__ gpart, int nslots, int l,
+                                                                 double* __restrict__ G, int64_t ldg, int accumulate) {
+  constexpr int NPAIR = C * (C + 1) / 2;
+  __shared__ double part[8][32];
+  const int j = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int pair = blockIdx.x >> 5, i = blockIdx.x & 31;
+  const size_t off = (size_t)pair * 1024 + (size_t)i * 32 + j;
+  double s = 0.0;
+  for (int k = sl; k < nslots; k += 8) s += (double)gpart[(size_t)k * (NPAIR * 1024) + off];
+  part[sl][j] = s;
+  __syncthreads();
+  if (sl != 0) return;
+#pragma unroll
+  for (int q = 1; q < 8; ++q) s += part[q][j];
+  int c1 = 0, c2 = 0, p = pair;
+  for (c1 = 0; c1 < C; ++c1) {
+    if (p < C - c1) { c2 = c1 + p; break; }
+    p -= C - c1;
+  }
+  const int gi = 32 * c1 + i, gj = 32 * c2 + j;
+  if (gi >= l || gj >= l) return;
+  if (accumulate) {
+    G[(int64_t)gi * ldg + gj] += s;
+    if (c1 != c2) G[(int64_t)gj * ldg + gi] += s;
+  } else {
+    G[(int64_t)gi * ldg + gj] = s;
+    if (c1 != c2) G[(int64_t)gj * ldg + gi] = s;
+  }
+}
+
 template <int C>
 int launch_skinny(const float* X, int64_t m, int64_t n, int64_t ldx, const float* W, int64_t ldw,
-                  int l, float* Y, int64_t ldy, hipStream_t stream) {
+                  int l, float* Y, int64_t ldy, hipStream_t stream, float* gpart = nullptr, double* G = nullptr,
+                  int64_t ldg = 0, int accumulate = 0) {
   const bool aligned = (m % 4 == 0) && (m >= 4) && (ldx % 4 == 0) && (ldw % 4 == 0) &&
                        (ldy % 4 == 0) && dmdx_aligned16(X) && dmdx_aligned16(W) &&
                        dmdx_aligned16(Y);
   dim3 grid((unsigned)((m + ROWS_PER_WG - 1) / ROWS_PER_WG));
-  if (aligned)
-    hipLaunchKernelGGL((skinny_kernel<C, true>), grid, dim3(256), 0, stream, X, m, n, ldx, W, ldw, l,
-                       Y, ldy, dmdx_clock_probe_ptr);
-  else
-    hipLaunchKernelGGL((skinny_kernel<C, false>), grid, dim3(256), 0, stream, X, m, n, ldx, W, ldw,
-                       l, Y, ldy, dmdx_clock_probe_ptr);
+  if constexpr (C <= 3) {   // (the fused Gram at C = 4 would spill: 256 accumulator registers + the 32 x 32 tile)
+    if (gpart != nullptr) {
+      if (aligned)
+        hipLaunchKernelGGL((skinny_kernel<C, true, true>), grid, dim3(256), 0, stream, X, m, n, ldx, W, ldw, l,
+                           Y, ldy, dmdx_clock_probe_ptr, gpart);
+      else
+        hipLaunchKernelGGL((skinny_kernel<C, false, true>), grid, dim3(256), 0, stream, X, m, n, ldx, W, ldw,
+                           l, Y, ldy, dmdx_clock_probe_ptr, gpart);
+    }
+  }
+  if (gpart == nullptr || C > 3) {
+    if (aligned)
+      hipLaunchKernelGGL((skinny_kernel<C, true>), grid, dim3(256), 0, stream, X, m, n, ldx, W, ldw, l,
+                         Y, ldy, dmdx_clock_probe_ptr, nullptr);
+    else
+      hipLaunchKernelGGL((skinny_kernel<C, false>), grid, dim3(256), 0, stream, X, m, n, ldx, W, ldw,
+                         l, Y, ldy, dmdx_clock_probe_ptr, nullptr);
+  }
   DMDX_LAUNCH_CHECK();
+  if (gpart != nullptr && C <= 3) {
+    constexpr int NPAIR = C * (C + 1) / 2;
+    hipLaunchKernelGGL(skinny_gram_reduce_kernel<C>, dim3(NPAIR * 32), dim3(256), 0, stream, gpart,
+                       (int)grid.x * 4, l, G, ldg, accumulate);
+    DMDX_LAUNCH_CHECK();
+  }
   return 0;
 }
 
@@ -320,4 +414,31 @@ extern "C" int dmdx_gemm_nn_skinny_f32(const float* X, int64_t m, int64_t n, int
     if (rc) return rc;
   }
   return 0;
+}
+
+extern "C" size_t dmdx_gemm_nn_skinny_gram_workspace_bytes(int64_t m, int64_t l) {
+  if (m < 1 || l < 1 || l > 96) return 0;
+  const size_t c = (size_t)((l + 31) / 32);
+  return (size_t)((m + ROWS_PER_WG - 1) / ROWS_PER_WG) * 4 * (c * (c + 1) / 2) * 1024 * sizeof(float);
+}
+
+extern "C" int dmdx_gemm_nn_skinny_gram_f32(const float* X, int64_t m, int64_t n, int64_t ldx, const float* W,
+                                            int64_t ldw, int64_t l, float* Y, int64_t ldy, double* G, int64_t ldg,
+                                            int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+  DMDX_CHECK_ARG(X && W && Y && G, "skinny_gram: null pointer");
+  DMDX_CHECK_ARG(m >= 1 && n >= 1 && l >= 1 && l <= 96, "skinny_gram: bad shape m=%lld n=%lld l=%lld (l <= 96)",
+                 (long long)m, (long long)n, (long long)l);
+  DMDX_CHECK_ARG(ldx >= 1 && ldw >= n && ldy >= m && ldg >= l, "skinny_gram: bad leading dimension");
+  DMDX_CHECK_ARG(m + 4 * ldx < (1ll << 29), "skinny_gram: m + 4 ldx >= 2^29 not supported");
+  const size_t need = dmdx_gemm_nn_skinny_gram_workspace_bytes(m, l);
+  if (workspace == nullptr || workspace_bytes < need) {
+    dmdx_set_error("skinny_gram: workspace %zu bytes < required %zu", workspace_bytes, need);
+    return DMDX_E_WORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  float* gp = reinterpret_cast<float*>(workspace);
+  const int li = (int)l;
+  if (l <= 32) return launch_skinny<1>(X, m, n, ldx, W, ldw, li, Y, ldy, st, gp, G, ldg, accumulate);
+  if (l <= 64) return launch_skinny<2>(X, m, n, ldx, W, ldw, li, Y, ldy, st, gp, G, ldg, accumulate);
+  return launch_skinny<3>(X, m, n, ldx, W, ldw, li, Y, ldy, st, gp, G, ldg, accumulate);
 }

@@ -210,11 +210,16 @@ class HipKernels:
         Wp[:, :n] = Wt
         return Wp[:, :n]
 
-    def skinny(self, Xt: torch.Tensor, Wt: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+    skinny_gram_max_l = 96
+
+    def skinny(self, Xt: torch.Tensor, Wt: torch.Tensor, out: torch.Tensor | None = None,
+               gram: torch.Tensor | None = None) -> torch.Tensor:
         """Y = X W.  Xt: (n, m), Wt: (l, n) fp32 -> Yt: (l, m) fp32.
 
         ``out``: an (l, m) fp32 view to write into (inner stride 1, any row stride >= m) -- a
-        column slice of the (l, M) result of all row blocks, so that no concatenation follows."""
+        column slice of the (l, M) result of all row blocks, so that no concatenation follows.
+        ``gram``: an (l, l) fp64 tensor (l <= skinny_gram_max_l) that Y^T Y is ADDED to, formed from
+        the accumulators inside the same launch (the Gram of the CholeskyQR round that follows)."""
         m, n, ldx = _check_mat(Xt, torch.float32, "skinny X")
         nw, l, ldw = _check_mat(Wt, torch.float32, "skinny W")
         if nw != n:
@@ -228,6 +233,18 @@ class HipKernels:
             Yt = out
         else:
             Yt, ldy = torch.empty((l, m), dtype=torch.float32, device=Xt.device), m
+        if gram is not None:
+            if gram.shape != (l, l) or gram.dtype != torch.float64 or not gram.is_contiguous() or gram.device != Xt.device \
+                    or l > self.skinny_gram_max_l:
+                raise _lib.DmdxError(f"skinny: gram must be a contiguous ({l}, {l}) fp64 tensor on {Xt.device}, "
+                                     f"l <= {self.skinny_gram_max_l}")
+            ws = self._workspace(Xt.device, self._lib.dmdx_gemm_nn_skinny_gram_workspace_bytes(m, l))
+            rc = self._timed("skinny_gram", (m, n, l), lambda: self._lib.dmdx_gemm_nn_skinny_gram_f32(
+                _ptr(Xt), m, n, ldx, _ptr(Wt), ldw, l, _ptr(Yt), ldy, _ptr(gram), l, 1, _ptr(ws), ws.numel(),
+                self._stream()
+            ))
+            _lib.check(rc, "dmdx_gemm_nn_skinny_gram_f32")
+            return Yt
         rc = self._timed("skinny", (m, n, l), lambda: self._lib.dmdx_gemm_nn_skinny_f32(
             _ptr(Xt), m, n, ldx, _ptr(Wt), ldw, l, _ptr(Yt), ldy, self._stream()
         ))

@@ -1101,10 +1101,23 @@ def svd_randomized_streaming(pieces, n_components: int, rows_global: int, n_time
 # ---------------------------------------------------------------------------
 # "randomized": sklearn's range finder with CholeskyQR normalisers
 # ---------------------------------------------------------------------------
-def _cholqr(Yb, comm: Comm, kern, passes: int = 1):
+def _project_with_gram(kern, Eb, Qp, comm: Comm):
+    """[E_b Q for every row block] and, where the provider can fuse it into the same launches
+    (K2 with l <= 96), the Gram G = sum_b Y_b^T Y_b of the result, summed over the ranks: what the
+    CholeskyQR round that follows starts from -- otherwise None (the round computes it itself, one
+    more pass over the m x l matrix)."""
+    l = int(Qp.shape[0])
+    if l <= getattr(kern, "skinny_gram_max_l", 0):
+        G0 = torch.zeros((l, l), dtype=torch.float64, device=Eb[0].device)
+        Yb = [kern.skinny(E, Qp, gram=G0) for E in Eb]
+        return Yb, comm.allreduce_sum_(G0)
+    return [kern.skinny(E, Qp) for E in Eb], None
+
+
+def _cholqr(Yb, comm: Comm, kern, passes: int = 1, G0: torch.Tensor | None = None):
     """Orthonormalise the columns of the tall matrix Y given as row blocks
-    (each (l, M_b)): G = Y^T Y (l x l, summed over blocks and ranks), G = R^T R,
-    Y <- Y R^-1.
+    (each (l, M_b)): G = Y^T Y (l x l, summed over blocks and ranks; ``G0``: that Gram for the
+    first pass, when the launches that produced Y already formed it), G = R^T R, Y <- Y R^-1.
 
     CholeskyQR needs cond(Y)^2 below the accuracy of the fp32-product Gram (~1e8).  Oversampled
     range-finder blocks reach past the numerical rank of X, so when the factorisation fails (or
@@ -1117,7 +1130,7 @@ def _cholqr(Yb, comm: Comm, kern, passes: int = 1):
     while todo > 0 and done < passes + 3:
         done += 1
         todo -= 1
-        G = _gram_blocks(Yb, kern, comm)
+        G = G0 if (G0 is not None and done == 1) else _gram_blocks(Yb, kern, comm)   # G0: fused into the K2 launches
         G = 0.5 * (G + G.T)
         L, err = torch.linalg.cholesky_ex(G)
         diag = torch.diagonal(L)
@@ -1207,9 +1220,11 @@ def svd_randomized(Xt, n_components: int, delay: int = 1, n_oversamples: int = 1
 
     for _ in range(n_it):
         Qp = _pitched(kern, Qt)
-        Yb = [kern.skinny(E, Qp) for E in Eb]    # Y = X Q            (extmath.py:350)
         if normalise:
-            Yb = _cholqr(Yb, comm, kern)
+            Yb, G0 = _project_with_gram(kern, Eb, Qp, comm)   # Y = X Q (extmath.py:350) + its Gram
+            Yb = _cholqr(Yb, comm, kern, G0=G0)
+        else:
+            Yb = [kern.skinny(E, Qp) for E in Eb]
         Zt = _gemm_tn_blocks(Eb, Yb, kern, comm)  # Z = X^T Y, (l, nd) (extmath.py:351)
         if normalise:
             Qt = _orth(Zt.T).T.contiguous().to(torch.float32)
@@ -1217,8 +1232,8 @@ def svd_randomized(Xt, n_components: int, delay: int = 1, n_oversamples: int = 1
             Qt = Zt.to(torch.float32)
         comm.broadcast_(Qt)
     Qp = _pitched(kern, Qt)
-    Yb = [kern.skinny(E, Qp) for E in Eb]        # extmath.py:355
-    Qmb = _cholqr(Yb, comm, kern, passes=2)      # orthonormal basis of range(Y)
+    Yb, G0 = _project_with_gram(kern, Eb, Qp, comm)        # extmath.py:355
+    Qmb = _cholqr(Yb, comm, kern, passes=2, G0=G0)         # orthonormal basis of range(Y)
     Bm = _gemm_tn_blocks(Eb, Qmb, kern, comm)    # (l, nd) = Q^T X    (extmath.py:577)
     Uhat, s, Vh = torch.linalg.svd(Bm, full_matrices=False)
     Uhat, s, Vh = Uhat.contiguous(), s.contiguous(), Vh.contiguous()

@@ -102,6 +102,17 @@ int dmdx_gemm_nn_skinny_f32(const float* X, int64_t m, int64_t n, int64_t ldx,
                             const float* W, int64_t ldw, int64_t l,
                             float* Y, int64_t ldy, void* stream);
 
+/* K2 with the Gram of its output fused in: Y = X W as above (l <= 96) and G (+)= Y^T Y (l x l fp64,
+ * ldg, both triangles), formed from the accumulators before they leave the registers: the
+ * CholeskyQR rounds of the range finder (the LU / QR normalisers of extmath.py:349-355 in this
+ * engine) need that Gram, and computing it separately is another pass over the m x l matrix.
+ * Per-(workgroup, wave) fp32 partial tiles in the workspace, summed in fp64 (deterministic). */
+size_t dmdx_gemm_nn_skinny_gram_workspace_bytes(int64_t m, int64_t l);
+int dmdx_gemm_nn_skinny_gram_f32(const float* X, int64_t m, int64_t n, int64_t ldx,
+                                 const float* W, int64_t ldw, int64_t l, float* Y, int64_t ldy,
+                                 double* G, int64_t ldg, int accumulate,
+                                 void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- K5: per-row (space point) mean / std over time, centre, scale ---------
  * slice_tools.py:171-179.  X: m x n (ldx) modified in place:
  *   mean[i] = sum_j X[i,j] / n ; X[i,:] -= mean[i];

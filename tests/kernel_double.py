@@ -39,8 +39,12 @@ class CpuKernelDouble:
             Cm = self.gemm_tn(A, B) if Cm is None else self.gemm_tn(A, B, out=Cm)
         return Cm
 
-    def skinny(self, Xt, Wt, out=None):
+    skinny_gram_max_l = 96
+
+    def skinny(self, Xt, Wt, out=None, gram=None):
         Y = (Wt.to(torch.float64) @ Xt.to(torch.float64)).float()
+        if gram is not None:
+            gram += Y.double() @ Y.double().T
         if out is None:
             return Y
         out.copy_(Y)

@@ -118,6 +118,37 @@ def test_skinny(K, m, n, l):
     assert np.all(np.abs(Yt - ref) <= (4 + np.sqrt(n)) * EPS32 * absref + 1e-30)
 
 
+@pytest.mark.parametrize("m,n,l", [(4, 2, 1), (512, 32, 32), (1003, 64, 20), (4096, 192, 60), (5000, 191, 70),
+                                   (130000, 96, 96), (777, 33, 64), (2048, 3653, 70)])
+def test_skinny_with_fused_gram(K, m, n, l):
+    """K2 with the Gram of its output formed from the accumulators in the same launch: Y must be
+    bit-identical to the plain K2 launch and G = Y^T Y (of the stored fp32 Y, fp64 reference)
+    within 4e-6 sum|y||y| (fp32 MFMA chains of 128 rows, fp64 across waves and workgroups) --
+    including row counts that are not multiples of 512 / 128 / 4 (the clamped rows past the end
+    must not be counted), l not a multiple of 32, and accumulation over row blocks."""
+    rs = np.random.RandomState(m + 13 * n + 7 * l)
+    X = _rand(rs, m, n)
+    W = _rand(rs, n, l)
+    Xt, Wt = _dev(X.T), _dev(W.T)
+    Y0 = K.skinny(Xt, Wt)
+    G = torch.zeros((l, l), dtype=torch.float64, device="cuda")
+    Y1 = K.skinny(Xt, Wt, gram=G)
+    assert torch.equal(Y0, Y1)
+    Yd = Y1.double()
+    ref = Yd @ Yd.T
+    bound = 4e-6 * (Yd.abs() @ Yd.abs().T) + 1e-30
+    assert bool(((G - ref).abs() <= bound).all()) and torch.equal(G, G.T)
+    K.skinny(Xt, Wt, gram=G)                                    # accumulates
+    assert bool(((G - 2 * ref).abs() <= 2 * bound).all())
+    G2 = torch.zeros_like(G)
+    K.skinny(Xt, Wt, gram=G2)
+    assert torch.equal(G2 * 2, G) or bool(((G2 * 2 - G).abs() <= 1e-12 * ref.abs().max()).all())   # deterministic
+    from dmd_era5_amd._lib import DmdxError
+
+    with pytest.raises(DmdxError):
+        K.skinny(Xt, Wt, gram=torch.zeros((l, l), dtype=torch.float32, device="cuda"))
+
+
 def test_skinny_on_delay_view_equals_explicit_embedding(K):
     """rows > ld: the zero-copy embedded view must give the same product as the
     materialised embedding of the oracle (reference slice_tools.py:207-211)."""

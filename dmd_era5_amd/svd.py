@@ -1134,8 +1134,9 @@ def _cholqr(Yb, comm: Comm, kern, passes: int = 1, G0: torch.Tensor | None = Non
         G = 0.5 * (G + G.T)
         L, err = torch.linalg.cholesky_ex(G)
         diag = torch.diagonal(L)
-        bad = int(err) != 0 or not bool(torch.isfinite(diag).all()) or \
-            float(diag.min()) < 1e-4 * float(diag.max())
+        # (one read-back for the three checks: every host round trip is a bubble in the launch stream)
+        bad = bool(torch.logical_or(torch.logical_or(err != 0, ~torch.isfinite(diag).all()),
+                                    diag.min() < 1e-4 * diag.max()))
         if bad:
             # (the Gram of fp32 products can be indefinite by more than 1e-6 of its trace --
             # identical values accumulate their rounding coherently -- so the shift escalates)
@@ -1227,7 +1228,7 @@ def svd_randomized(Xt, n_components: int, delay: int = 1, n_oversamples: int = 1
             Yb = [kern.skinny(E, Qp) for E in Eb]
         Zt = _gemm_tn_blocks(Eb, Yb, kern, comm)  # Z = X^T Y, (l, nd) (extmath.py:351)
         if normalise:
-            Qt = _orth(Zt.T).T.contiguous().to(torch.float32)
+            Qt = _orth(Zt.T.contiguous(), kern=kern).T.contiguous().to(torch.float32)
         else:
             Qt = Zt.to(torch.float32)
         comm.broadcast_(Qt)

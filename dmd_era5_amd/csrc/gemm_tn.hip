@@ -842,6 +842,253 @@ int run_batch(const float* const* A, const int64_t* lda, const float* const* B, 
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// K3s: D (nb x na) (+)= sum_j Y_j^T X_j for nb <= 32 (the HBM-bound small-l products of the range
+// finder at the reference's default n_components = 10, l = 20; the single-column product
+// w = A^T mu of the mean deflation).  The generic body above stages 32-row chunks: every LDS-DMA
+// piece is 8 columns x 128 B, i.e. every 128-byte request opens another DRAM page of a matrix
+// whose columns are 0.5 MB apart, and the pass over cfg2's X runs at 4.85 TB/s where K2 (1 KB
+// runs) streams the same bytes at 6.0 TB/s.  Here a chunk is 64 rows -- pieces of 4 columns x
+// 256 B -- and the four waves of a workgroup split the ROWS of a chunk (16 each) instead of the
+// columns of the tile, so that one workgroup still covers 128 time columns with 40 KB per stage:
+//   tile  = 32 (l) x 128 (time columns), unit = (row block, K split, tile), 2 workgroups per CU;
+//   stage = Y panel [32 col][64 k] + X panel [128 col][64 k] fp32, 16-byte k-pieces XOR-swizzled
+//           with (col & 15) on the DMA source and on the fragment reads (conflict-free b128);
+//   wave w contracts rows 16 w .. 16 w + 15 of every chunk: 2 k-steps x (1 + 4) ds_read_b128 and
+//           32 MFMAs per chunk; fp32 chains of <= 2048 rows folded into a second accumulator;
+//   end of unit: the four waves' 32 x 128 accumulators meet in LDS, one fp64 partial tile per
+//           unit (no atomics), a second kernel sums the units of a tile into D.
+// Rows beyond the last full 64-row chunk of a block (K % 64) go through the generic path
+// (one extra batched launch over the tails, accumulate).
+constexpr int XT = 128, XL = 32, XK = 64;
+constexpr int XSTG = (XL + XT) * XK;   // floats per stage: 40 KB
+constexpr int XFOLD = 128;             // chunks per fp32 chain (16 rows of each per wave: 2048 rows)
+
+struct XtyBatch {
+  const float* X[MAXB];   // big operand (D cols): K x na, ldx
+  const float* Y[MAXB];   // small operand (D rows): K x nb, ldy
+  int64_t ldx[MAXB], ldy[MAXB];
+  int chunks[MAXB], cps[MAXB], nsplit[MAXB];
+  int unit_begin[MAXB + 1];
+  int nblocks, ntiles, na, nb;
+  double* P;              // [unit][32][128] fp64
+};
+
+__device__ __forceinline__ void xty_dma(unsigned lds_addr, unsigned off, const char* base) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+               :: "s"(lds_addr), "v"(off), "s"(base) : "memory");
+}
+
+__global__ __launch_bounds__(NTH, 2) void xty_small_kernel(XtyBatch bt) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * XSTG];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int u = blockIdx.x;
+  int j = 0;
+  while (j + 1 < bt.nblocks && u >= bt.unit_begin[j + 1]) ++j;
+  const int local = u - bt.unit_begin[j];
+  const int split = local / bt.ntiles, tile = local - split * bt.ntiles;
+  const int c_begin = split * bt.cps[j];
+  int c_end = c_begin + bt.cps[j];
+  if (c_end > bt.chunks[j]) c_end = bt.chunks[j];
+  const int nch = c_end - c_begin;
+  const int col0 = tile * XT;
+  const int64_t ldx = bt.ldx[j], ldy = bt.ldy[j];
+  const int cb0 = col0 < bt.na ? col0 : bt.na - 1;
+  const char* Xb = reinterpret_cast<const char*>(bt.X[j] + (int64_t)cb0 * ldx) + (int64_t)c_begin * XK * 4;
+  const char* Yb = reinterpret_cast<const char*>(bt.Y[j]) + (int64_t)c_begin * XK * 4;
+
+  // per-lane source byte offsets of this wave's pieces (columns past the edge clamp onto the last one)
+  unsigned xoff[8], yoff[2];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int lc = 32 * wave + 4 * i + (lane >> 4);
+    int cg = col0 + lc;
+    cg = cg < bt.na ? cg : bt.na - 1;
+    const int g = (lane & 15) ^ (lc & 15);
+    xoff[i] = (unsigned)(((int64_t)(cg - cb0) * ldx + 4 * g) * 4);
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int lc = 8 * wave + 4 * i + (lane >> 4);
+    const int cg = lc < bt.nb ? lc : bt.nb - 1;
+    const int g = (lane & 15) ^ (lc & 15);
+    yoff[i] = (unsigned)(((int64_t)cg * ldy + 4 * g) * 4);
+  }
+  auto issue = [&](int c, int st) {
+    const char* xb = Xb + (int64_t)c * (XK * 4);
+    const char* yb = Yb + (int64_t)c * (XK * 4);
+    float* ys = lds + st * XSTG + (8 * wave) * XK;
+    float* xs = lds + st * XSTG + XL * XK + (32 * wave) * XK;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) xty_dma((unsigned)(uintptr_t)DMDX_LDS_PTR(ys + 4 * i * XK), yoff[i], yb);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) xty_dma((unsigned)(uintptr_t)DMDX_LDS_PTR(xs + 4 * i * XK), xoff[i], xb);
+  };
+
+  f32x16 acc[4], acc2[4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[b][r] = 0.f; acc2[b][r] = 0.f; }
+
+  if (nch > 0) issue(0, 0);
+  if (nch > 1) issue(1, 1);
+  const int sw = l31 & 15;
+  for (int c = 0; c < nch; ++c) {
+    const int st = c & 1;
+    if (c + 1 < nch) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");   // this wave's 10 pieces of chunk c have landed
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const float* ys = lds + st * XSTG;
+    const float* xs = ys + XL * XK;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const int c16 = 4 * wave + 2 * s2 + lh;
+      const int ko = 4 * (c16 ^ sw);
+      const f32x4 fa = *reinterpret_cast<const f32x4*>(ys + l31 * XK + ko);
+      f32x4 fb[4];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) fb[b] = *reinterpret_cast<const f32x4*>(xs + (32 * b + l31) * XK + ko);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[e], fb[b][e], acc[b], 0, 0, 0);
+    }
+    __syncthreads();   // every wave has read stage st for the last time
+    if (c + 2 < nch) issue(c + 2, st);
+    if ((c & (XFOLD - 1)) == XFOLD - 1) {
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        acc2[b] += acc[b];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+      }
+    }
+  }
+  // ---- the four waves' partial tiles meet in LDS (64 KB of the 80), wave w finishes column block w
+  float* red = lds;
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+      red[wave * (XL * XT) + ((q & 3) + 8 * (q >> 2) + 4 * lh) * XT + 32 * b + l31] = acc[b][q] + acc2[b][q];
+  __syncthreads();
+  double* Pt = bt.P + (size_t)u * (XL * XT);
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int i = (q & 3) + 8 * (q >> 2) + 4 * lh;
+    const int o = i * XT + 32 * wave + l31;
+    const double v = (double)red[o] + (double)red[XL * XT + o] + (double)red[2 * XL * XT + o] + (double)red[3 * XL * XT + o];
+    __builtin_nontemporal_store(v, Pt + o);
+  }
+}
+
+// D[i][col] (+)= sum over the units of tile (col / 128) of their partial tiles
+__global__ __launch_bounds__(128) void xty_small_reduce_kernel(XtyBatch bt, double* D64, int64_t ld64, int accumulate) {
+  const int tile = blockIdx.x, i = blockIdx.y, jj = threadIdx.x;
+  const int col = tile * XT + jj;
+  if (i >= bt.nb || col >= bt.na) return;
+  double s = 0.0;
+  for (int j = 0; j < bt.nblocks; ++j)
+    for (int sp = 0; sp < bt.nsplit[j]; ++sp)
+      s += bt.P[(size_t)(bt.unit_begin[j] + sp * bt.ntiles + tile) * (XL * XT) + i * XT + jj];
+  double* d = D64 + (int64_t)i * ld64 + col;
+  *d = accumulate ? *d + s : s;
+}
+
+bool xty_small_ok(const float* const* X, const int64_t* ldx, const float* const* Y, const int64_t* ldy,
+                  const int64_t* K, int nblocks, int64_t nb, int64_t na, const float* D32) {
+  if (getenv("DMDX_NO_K3S")) return false;   // A/B knob
+  if (D32 || nb > XL || na < XT) return false;
+  for (int j = 0; j < nblocks; ++j) {
+    if (K[j] < 8 * XK || ldx[j] % 4 || ldy[j] % 4 || !dmdx_aligned16(X[j]) || !dmdx_aligned16(Y[j])) return false;
+    if (ldx[j] >= (int64_t(1) << 22) || ldy[j] >= (int64_t(1) << 22)) return false;
+  }
+  return true;
+}
+
+void xty_small_plan(const int64_t* K, int nb_, int ntiles, int* chunks, int* cps, int* nsplit, int* units) {
+  int total = 0;
+  for (int j = 0; j < nb_; ++j) {
+    chunks[j] = (int)(K[j] / XK);
+    int64_t want = (4 * 512 + (int64_t)ntiles * nb_ - 1) / ((int64_t)ntiles * nb_);   // ~4 rounds of 512 workgroups
+    const int64_t maxs = chunks[j] / 16 > 0 ? chunks[j] / 16 : 1;
+    if (want > maxs) want = maxs;
+    if (want < 1) want = 1;
+    cps[j] = (int)((chunks[j] + want - 1) / want);
+    nsplit[j] = (chunks[j] + cps[j] - 1) / cps[j];
+    total += nsplit[j] * ntiles;
+  }
+  *units = total;
+}
+
+size_t xty_small_ws(const int64_t* K, int nblocks, int64_t na) {
+  const int ntiles = (int)((na + XT - 1) / XT);
+  size_t need = 0;
+  for (int j0 = 0; j0 < nblocks; j0 += MAXB) {
+    const int ng = nblocks - j0 < MAXB ? nblocks - j0 : MAXB;
+    int ch[MAXB], cp[MAXB], ns[MAXB], units = 0;
+    xty_small_plan(K + j0, ng, ntiles, ch, cp, ns, &units);
+    const size_t g = (size_t)units * XL * XT * sizeof(double);
+    if (g > need) need = g;
+  }
+  return need;
+}
+
+int run_xty_small(const float* const* X, const int64_t* ldx, const float* const* Y, const int64_t* ldy,
+                  const int64_t* K, int nblocks, int64_t nb, int64_t na, double* D64, int64_t ld64, int accumulate,
+                  void* ws, size_t ws_bytes, hipStream_t stream) {
+  const int ntiles = (int)((na + XT - 1) / XT);
+  if (ws == nullptr || ws_bytes < xty_small_ws(K, nblocks, na)) {
+    dmdx_set_error("gemm_tn_blocks (small-l path): workspace %zu bytes too small", ws_bytes);
+    return DMDX_E_WORKSPACE;
+  }
+  for (int j0 = 0; j0 < nblocks; j0 += MAXB) {
+    const int ng = nblocks - j0 < MAXB ? nblocks - j0 : MAXB;
+    XtyBatch bt{};
+    int units = 0;
+    xty_small_plan(K + j0, ng, ntiles, bt.chunks, bt.cps, bt.nsplit, &units);
+    int ub = 0;
+    for (int j = 0; j < ng; ++j) {
+      bt.X[j] = X[j0 + j];
+      bt.Y[j] = Y[j0 + j];
+      bt.ldx[j] = ldx[j0 + j];
+      bt.ldy[j] = ldy[j0 + j];
+      bt.unit_begin[j] = ub;
+      ub += bt.nsplit[j] * ntiles;
+    }
+    bt.unit_begin[ng] = ub;
+    bt.nblocks = ng;
+    bt.ntiles = ntiles;
+    bt.na = (int)na;
+    bt.nb = (int)nb;
+    bt.P = reinterpret_cast<double*>(ws);
+    hipLaunchKernelGGL(xty_small_kernel, dim3((unsigned)units), dim3(NTH), 0, stream, bt);
+    DMDX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(xty_small_reduce_kernel, dim3((unsigned)ntiles, (unsigned)nb), dim3(XT), 0, stream, bt, D64, ld64,
+                       (accumulate || j0 > 0) ? 1 : 0);
+    DMDX_LAUNCH_CHECK();
+  }
+  // rows past the last full 64-row chunk of every block: the generic path, accumulated on top
+  std::vector<const float*> Xt, Yt;
+  std::vector<int64_t> lx, ly, Kt;
+  for (int j = 0; j < nblocks; ++j) {
+    const int64_t tail = K[j] % XK;
+    if (tail == 0) continue;
+    Xt.push_back(X[j] + (K[j] - tail));
+    Yt.push_back(Y[j] + (K[j] - tail));
+    lx.push_back(ldx[j]);
+    ly.push_back(ldy[j]);
+    Kt.push_back(tail);
+  }
+  if (!Kt.empty())
+    return run_batch(Yt.data(), ly.data(), Xt.data(), lx.data(), Kt.data(), (int)Kt.size(), nb, na, 0, D64, ld64, nullptr,
+                     0, 1, ws, ws_bytes, stream);
+  return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -966,6 +1213,10 @@ size_t dmdx_gemm_tn_blocks_workspace_bytes(const int64_t* K, int nblocks, int64_
     }
     if (g > need) need = g;
   }
+  if (nb <= XL && na >= XT) {   // the small-l path (K3s) has its own partial tiles
+    const size_t x = xty_small_ws(K, nblocks, na);
+    if (x > need) need = x;
+  }
   return need;
 }
 
@@ -979,6 +1230,9 @@ int dmdx_gemm_tn_blocks_f32(const float* const* A, const int64_t* lda, const flo
   for (int j = 0; j < nblocks; ++j)
     DMDX_CHECK_ARG(A[j] && B[j] && K[j] >= 1 && lda[j] >= 1 && ldb[j] >= 1, "gemm_tn_blocks: bad block %d", j);
   // column-major C[a + b*ldc] == row-major D[b][a]: D rows <- B columns, D cols <- A columns
+  if (xty_small_ok(A, lda, B, ldb, K, nblocks, nb, na, C32))
+    return run_xty_small(A, lda, B, ldb, K, nblocks, nb, na, C64, ldc, accumulate, workspace, workspace_bytes,
+                         (hipStream_t)stream);
   if (const int64_t cut = tn_row_split(nb)) {
     const int rc = run_batch(B, ldb, A, lda, K, nblocks, cut, na, 0, C64, ldc, C32, ldc32, accumulate, workspace,
                              workspace_bytes, (hipStream_t)stream);

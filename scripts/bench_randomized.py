@@ -48,7 +48,7 @@ out = {"metric": "randomized rank-r SVD GB/s on ERA5 snapshot matrix (X resident
        "config": {"workload": desc.replace("method-of-snapshots", "randomized (sklearn defaults)"), "k": a.k,
                   "l": l, "n_iter": int(res.info["n_iter"]), "passes_over_X": 2 * int(res.info["n_iter"]) + 2},
        "kernels": {}}
-for name, label in (("skinny", "K2 skinny_kernel (Y = X Q)"), ("gemm_tn", "K3 gemm_tn_partial_kernel 64x128 tiles (Z = X^T Y)")):
+for name, label in (("skinny", "K2 skinny_kernel (Y = X Q)"), ("gemm_tn", "K3 (Z = X^T Y: 64x128-tile generic body, or K3s at l <= 32)")):
     if not rows[name]:
         continue
     mb = float(np.mean([r[0] for r in rows[name]]))
@@ -86,7 +86,7 @@ def probed(fn):
 
 
 for label, fn in (("K2 skinny_kernel (Y = X Q)", lambda: [kern.skinny(B, Qt) for B in blocks]),
-                  ("K3 gemm_tn_partial_kernel 64x128 tiles (Z = X^T Y)", lambda: kern.gemm_tn_blocks(blocks, Yb))):
+                  ("K3 (Z = X^T Y: 64x128-tile generic body, or K3s at l <= 32)", lambda: kern.gemm_tn_blocks(blocks, Yb))):
     if label not in out["kernels"]:
         continue
     mhz, ms_pass = probed(fn)

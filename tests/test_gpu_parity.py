@@ -776,6 +776,38 @@ def test_gemm_tn_blocks_equals_sum_of_block_products(K, sizes, na, nb):
     assert np.allclose(C2 + 2.0, Ct, rtol=0, atol=1e-9 * np.abs(ref).max())
 
 
+@pytest.mark.parametrize("sizes,na,nb", [([4096, 4096], 300, 20), ([5000, 3001, 4097], 260, 32), ([640] * 19, 129, 7),
+                                         ([30001, 29999], 1000, 1), ([129780, 129780], 8760, 20), ([70000], 515, 10)])
+def test_gemm_tn_blocks_small_l_path(K, sizes, na, nb):
+    """nb <= 32 takes K3s (64-row chunks, waves split the rows of a chunk): against the fp64 product
+    of the stacked rows with the bound of the generic path; block lengths that are not multiples
+    of 64 (the tails go through the generic kernel), na not a multiple of 128, nb = 1, > 16
+    blocks, accumulation into an existing C, determinism, and equality with the generic path
+    (DMDX_NO_K3S) to rounding."""
+    rs = np.random.RandomState(sum(sizes) + na + nb)
+    As = [_rand(rs, m, na) for m in sizes]
+    Bs = [_rand(rs, m, nb) for m in sizes]
+    Ad, Bd = [_dev(a.T) for a in As], [_dev(b.T) for b in Bs]
+    if len(sizes) == 1:
+        Ad, Bd = Ad * 2, [Bd[0], torch.zeros_like(Bd[0])]          # (the blocks entry point needs >= 2 blocks)
+    Ct = K.gemm_tn_blocks(Ad, Bd).cpu().numpy()               # (nb, na)
+    A, B = np.concatenate(As).astype(np.float64), np.concatenate(Bs).astype(np.float64)
+    ref = (A.T @ B).T
+    absref = (np.abs(A).T @ np.abs(B)).T
+    assert Ct.shape == (nb, na)
+    assert np.all(np.abs(Ct - ref) <= 2e-6 * absref + 1e-30)
+    assert np.array_equal(K.gemm_tn_blocks(Ad, Bd).cpu().numpy(), Ct)
+    C0 = torch.full((nb, na), -2.0, dtype=torch.float64, device="cuda")
+    C2 = K.gemm_tn_blocks(Ad, Bd, out=C0).cpu().numpy()
+    assert np.allclose(C2 + 2.0, Ct, rtol=0, atol=1e-9 * np.abs(ref).max())
+    os.environ["DMDX_NO_K3S"] = "1"
+    try:
+        Cg = K.gemm_tn_blocks(Ad, Bd).cpu().numpy()
+    finally:
+        del os.environ["DMDX_NO_K3S"]
+    assert np.all(np.abs(Cg - Ct) <= 4e-6 * absref + 1e-30)
+
+
 def test_uncentred_temperature_like_data_matches_numpy_fp64():
     """mean_center = False on temperature-like data (s_1 ~ 3e4 s_2): the plain Gram route loses
     the trailing singular values in the rounding of the fp32 products (76 % error on s_2 measured);

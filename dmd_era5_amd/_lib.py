@@ -55,6 +55,7 @@ SIGNATURES = {
     "dmdx_gemm_tn_f64": (C.c_int, [_p, _i64, _p, _i64, _i64, _i64, _i64, _p, _i64, _p, _sz, _p]),
     "dmdx_pack_triu_f64": (C.c_int, [_p, _i64, _i64, _p, _p]),
     "dmdx_unpack_triu_f64": (C.c_int, [_p, _i64, _p, _i64, _p]),
+    "dmdx_exp_basis": (C.c_int, [_p, _p, _i64, _i64, _p, _p, C.c_int, _p]),
     "dmdx_set_clock_probe": (C.c_int, [_p]),
     "dmdx_calib_mfma_f32": (C.c_int, [C.c_int, C.c_int, _p, C.POINTER(C.c_double), _p]),
 }

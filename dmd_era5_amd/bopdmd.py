@@ -68,6 +68,11 @@ def _phi(alpha: torch.Tensor, t: torch.Tensor, dtype: torch.dtype | None = None)
     out = dtype or alpha.dtype
     a = alpha.to(torch.complex128)
     tt = (t.real if t.is_complex() else t).to(torch.float64)
+    if a.is_cuda and out in (torch.complex64, torch.complex128):
+        # one launch of the HIP kernel (dmdx_exp_basis) instead of the outer product / exp / cast chain
+        from .kernels import default_kernels
+
+        return default_kernels().exp_basis(a, tt.to(a.device), out, want_w=False)[0]
     return torch.exp(tt[:, None] * a[None, :]).to(out)
 
 

@@ -218,7 +218,45 @@ __global__ __launch_bounds__(256) void scale_columns_kernel(float* __restrict__ 
     y[i] *= a;
 }
 
+// Phi[i][j] = exp(alpha_j t_i) (and W = diag(t) Phi), the exponential basis of the optimized-DMD
+// fit: the exponent is formed and range-reduced in fp64 whatever the output type -- |alpha| t
+// reaches 1.4e4 rad over a year of hourly snapshots, which fp32 carries to 1e-3 rad only --, one
+// launch instead of the outer product / exp / cast / scale chain of temporaries
+template <typename T>
+__global__ __launch_bounds__(256) void exp_basis_kernel(const double* __restrict__ alpha, const double* __restrict__ t,
+                                                        int64_t n, int64_t r, T* __restrict__ Phi, T* __restrict__ W) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= n * r) return;
+  const int64_t i = idx / r, j = idx - i * r;
+  const double ti = t[i];
+  const double e = exp(alpha[2 * j] * ti);
+  double sn, cs;
+  sincos(alpha[2 * j + 1] * ti, &sn, &cs);
+  const double re = e * cs, im = e * sn;
+  Phi[2 * idx] = (T)re;
+  Phi[2 * idx + 1] = (T)im;
+  if (W) {
+    W[2 * idx] = (T)(ti * re);
+    W[2 * idx + 1] = (T)(ti * im);
+  }
+}
+
 }  // namespace
+
+extern "C" int dmdx_exp_basis(const double* alpha, const double* t, int64_t n, int64_t r, void* Phi, void* W,
+                              int single_precision, void* stream) {
+  DMDX_CHECK_ARG(alpha && t && Phi, "exp_basis: null pointer");
+  DMDX_CHECK_ARG(n >= 1 && r >= 1 && n * r < (int64_t(1) << 40), "exp_basis: bad shape");
+  const dim3 grid((unsigned)((n * r + 255) / 256));
+  if (single_precision)
+    hipLaunchKernelGGL(exp_basis_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, alpha, t, n, r,
+                       reinterpret_cast<float*>(Phi), reinterpret_cast<float*>(W));
+  else
+    hipLaunchKernelGGL(exp_basis_kernel<double>, grid, dim3(256), 0, (hipStream_t)stream, alpha, t, n, r,
+                       reinterpret_cast<double*>(Phi), reinterpret_cast<double*>(W));
+  DMDX_LAUNCH_CHECK();
+  return 0;
+}
 
 extern "C" int dmdx_row_center_scale_f32(float* X, int64_t m, int64_t n, int64_t ldx, float* mean,
                                          float* sdev, int scale, void* stream) {

@@ -427,6 +427,23 @@ class HipKernels:
                    "dmdx_unpack_triu_f64")
         return A
 
+    # -- optimized DMD ---------------------------------------------------------
+    def exp_basis(self, alpha: torch.Tensor, t: torch.Tensor, dtype: torch.dtype, want_w: bool = True):
+        """Phi = exp(t alpha^T) (n, r) and W = diag(t) Phi in ``dtype`` (complex64 / complex128) from
+        complex128 alpha (r,) and fp64 t (n,) on the device: one launch, exponent in fp64."""
+        if alpha.dtype != torch.complex128 or t.dtype != torch.float64 or not (alpha.is_cuda and t.is_cuda):
+            raise _lib.DmdxError("exp_basis: alpha complex128 and t float64 device tensors expected")
+        if dtype not in (torch.complex64, torch.complex128):
+            raise _lib.DmdxError("exp_basis: dtype must be complex64 or complex128")
+        n, r = t.numel(), alpha.numel()
+        a = torch.view_as_real(alpha.contiguous()).contiguous()
+        Phi = torch.empty((n, r), dtype=dtype, device=t.device)
+        W = torch.empty((n, r), dtype=dtype, device=t.device) if want_w else None
+        rc = self._lib.dmdx_exp_basis(_ptr(a), _ptr(t.contiguous()), n, r, _ptr(Phi), _ptr(W),
+                                      int(dtype == torch.complex64), self._stream())
+        _lib.check(rc, "dmdx_exp_basis")
+        return Phi, W
+
     # -- measurement aid ------------------------------------------------------
     def clock_probe(self, counters: torch.Tensor | None) -> None:
         """Switch the per-workgroup clock stamps of the batched Gram launch on (3 zeroed device

@@ -188,6 +188,14 @@ int dmdx_gemm_tn_f64(const double* A, int64_t lda, const double* B, int64_t ldb,
 int dmdx_pack_triu_f64(const double* A, int64_t n, int64_t lda, double* packed, void* stream);
 int dmdx_unpack_triu_f64(const double* packed, int64_t n, double* A, int64_t lda, void* stream);
 
+/* ---- exponential basis of the optimized-DMD fit (BASELINE config 5; the reference announces the fit,
+ * README.md:85,139, and holds no code for it) -----------------------------------------------------
+ * Phi[i][j] = exp(alpha_j t_i), W = diag(t) Phi (nullable): alpha r complex128 (re, im interleaved),
+ * t n fp64, Phi / W n x r row-major complex64 (single_precision != 0) or complex128.  The exponent
+ * is formed and range-reduced in fp64 whatever the output type. */
+int dmdx_exp_basis(const double* alpha, const double* t, int64_t n, int64_t r, void* Phi, void* W,
+                   int single_precision, void* stream);
+
 /* ---- measurement aid (not on the path): sustained core clock of the Gram launches ----------
  * While dev_counters3 (3 device uint64, caller-zeroed) is set, every workgroup of the batched
  * launches (dmdx_syrk_blocks_f32, dmdx_gemm_tn_blocks_f32) and of dmdx_gemm_nn_skinny_f32 adds its

@@ -171,3 +171,26 @@ def test_trial_steps_into_overflow_are_rejected_not_fatal():
         bop.optdmd(H.to(torch.complex64), t, 4, alpha0=start)
     res = bop.optdmd(H.to(torch.complex64), t, 4, alpha0=torch.from_numpy(alpha * (1 + 2e-3)), maxiter=30)
     assert np.isfinite(res.rel_error) and _err(res.eigs.to(torch.complex128), alpha) < 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.complex64, torch.complex128])
+def test_exp_basis_kernel_matches_complex128_exp(dtype):
+    """dmdx_exp_basis against torch's complex128 exp of the fp64 exponent: the kernel's own
+    exponent arithmetic is fp64 whatever the output type, so complex128 output agrees to
+    1e-12 (phases up to 1.4e4 rad: fp64 range reduction) and complex64 output to one fp32
+    rounding; W = diag(t) Phi."""
+    from dmd_era5_amd.kernels import default_kernels
+
+    K = default_kernels()
+    rs = np.random.RandomState(0)
+    n, r = 8760, 200
+    t = torch.from_numpy(np.arange(n) / 24.0).cuda()
+    alpha = torch.from_numpy(-rs.uniform(1e-4, 3e-3, r) + 1j * 2 * np.pi * rs.uniform(0.02, 6.0, r)).cuda()
+    Phi, W = K.exp_basis(alpha, t, dtype)
+    ref = torch.exp(t[:, None].to(torch.complex128) * alpha[None, :])
+    tol = 1e-12 if dtype == torch.complex128 else 1.2e-7
+    assert Phi.dtype == dtype and Phi.shape == (n, r)
+    assert float((Phi.to(torch.complex128) - ref).abs().max()) < tol
+    assert float((W.to(torch.complex128) - t[:, None] * ref).abs().max()) < tol * 366
+    assert torch.equal(bop._phi(alpha, t, dtype), Phi)              # the fit's basis IS the kernel's output

@@ -39,7 +39,7 @@ events, kern.events = kern.events, None
 l = int(res.info["l"])
 rows = {"skinny": [], "gemm_tn": []}
 for name, shape, e0, e1 in events:
-    if name == "skinny" and shape[1] == n:        # (m_b, n, l): X streamed
+    if name in ("skinny", "skinny_gram") and shape[1] == n:        # (m_b, n, l): X streamed (with or without the fused Gram)
         rows["skinny"].append((shape[0], e0.elapsed_time(e1)))
     elif name in ("gemm_tn", "gemm_tn_blocks") and shape[0] > 4 * n:  # (K, na, nb[, blocks]): X streamed
         rows["gemm_tn"].append((shape[0], e0.elapsed_time(e1)))

@@ -709,6 +709,7 @@ def test_eigh_small_matches_lapack(K, n):
     A = (Qm * lam) @ Qm.T
     A = 0.5 * (A + A.T)
     w, V = K.eigh_small(_dev(A))
+    assert 1 <= K.last_eigh_sweeps < 30        # the kernel reports its sweeps; 30 = its limit = not converged (raises)
     w, V = w.cpu().numpy(), V.cpu().numpy()
     ref = np.linalg.eigvalsh(A)[::-1]
     assert np.all(np.diff(w) <= 0)

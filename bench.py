@@ -327,7 +327,9 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
         args.gpus = world
     # DMDX_BENCH_DEVICE / DMDX_DIST_BACKEND: rehearsal knobs (several ranks on ONE GPU over gloo,
-    # to exercise the N > 1 code path on a single-GPU box); the driver's runs use neither.
+    # to exercise the N > 1 code path on a single-GPU box); DMDX_BENCH_FORCE_DIST=1: take the
+    # torch.distributed path with ONE rank (the only way RCCL itself runs on a one-GPU box: every
+    # collective of the step goes through the nccl backend).  The driver's runs use none of them.
     dev_index = int(os.environ.get("DMDX_BENCH_DEVICE", local_rank))
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
@@ -338,7 +340,7 @@ def main():
     kern = default_kernels()  # fails loudly if libdmdx.so is missing
     backend = None
     devices = [{"rank": 0, "device_index": dev_index, "name": torch.cuda.get_device_name(device)}]
-    if world > 1:
+    if world > 1 or os.environ.get("DMDX_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -402,11 +404,13 @@ def main():
     # per-launch HIP events: ~20 launches per standard step (free); the randomized path issues
     # thousands of launches per step, where recording them would be the thing measured
     kern.events = [] if svd_type == "standard" else None
+    issued = comm.n_collectives
     t0 = time.perf_counter()
     for _ in range(args.steps):
         res = step()
     barrier()
     dt = time.perf_counter() - t0
+    issued = (comm.n_collectives - issued) / max(args.steps, 1)
     events, kern.events = (kern.events or []), None
     if dist is not None:
         tmax = torch.tensor([dt], dtype=torch.float64, device=device)
@@ -445,6 +449,7 @@ def main():
         },
         "world_size": world,
         "backend": backend,
+        "collectives_per_step": issued,     # what this rank handed to torch.distributed inside the timed region
         "devices": devices,
     }
     if svd_type == "standard":

@@ -414,7 +414,7 @@ def _device_pipeline(ds: Dataset, parsed_config: dict, comm=None, kern=None, dev
         free = torch.cuda.mem_get_info(device)[0] + max(
             0, torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device))
         fits = need <= free
-        if comm.world_size > 1:   # one decision for all ranks: the resident and the streaming path exchange differently
+        if comm.exchanges:   # one decision for all ranks: the resident and the streaming path exchange differently
             flags = comm.allgather(torch.tensor([1 if fits else 0], dtype=torch.int64, device=device))
             fits = all(int(f.item()) for f in flags)
         if not fits:
@@ -582,7 +582,7 @@ def _device_pipeline(ds: Dataset, parsed_config: dict, comm=None, kern=None, dev
 
         n = blocks[0].shape[0]
         # one rank: concatenate on the host (a device-side cat would hold X twice in HBM)
-        Xall = torch.cat(blocks, dim=1) if comm.world_size > 1 else torch.cat([b.cpu() for b in blocks], dim=1)
+        Xall = torch.cat(blocks, dim=1) if comm.exchanges else torch.cat([b.cpu() for b in blocks], dim=1)
         Xg = assemble(Xall, (n,))                        # (time, variable, level, lat, lon) on rank 0
         del Xall
         if root:
@@ -638,7 +638,9 @@ def _dist_comm():
     ``python -m torch.distributed.run --nproc-per-node N -m dmd_era5_amd.era5_svd`` (one process
     per GPU, RCCL) or inside an already initialised ``torch.distributed`` job.  Returns
     (comm, created) -- ``created``: the process group was made here and is torn down by main.
-    DMDX_DIST_BACKEND=gloo / DMDX_DEVICE=i: rehearsal knobs (several ranks on one GPU)."""
+    DMDX_DIST_BACKEND=gloo / DMDX_DEVICE=i: rehearsal knobs (several ranks on one GPU);
+    DMDX_COMM_FORCE=1: a one-rank process group whose collectives are all issued (RCCL itself on
+    a one-GPU box)."""
     import os
 
     import torch
@@ -646,10 +648,14 @@ def _dist_comm():
 
     from . import svd as dsvd
 
+    force = os.environ.get("DMDX_COMM_FORCE") == "1"
     if dist.is_available() and dist.is_initialized():
-        return (dsvd.TorchDistComm() if dist.get_world_size() > 1 else dsvd.Comm()), False
-    if int(os.environ.get("WORLD_SIZE", "1")) <= 1:
+        return (dsvd.TorchDistComm() if dist.get_world_size() > 1 or force else dsvd.Comm()), False
+    if int(os.environ.get("WORLD_SIZE", "1")) <= 1 and not force:
         return dsvd.Comm(), False
+    if force:
+        for key, val in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_PORT", "29533")):
+            os.environ.setdefault(key, val)
     dev = int(os.environ.get("DMDX_DEVICE", os.environ.get("LOCAL_RANK", "0")))
     torch.cuda.set_device(dev)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

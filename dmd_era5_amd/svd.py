@@ -57,6 +57,8 @@ class Comm:
 
     world_size = 1
     rank = 0
+    exchanges = False   # whether the collectives are issued (TorchDistComm: world_size > 1)
+    n_collectives = 0   # collectives issued so far (bench.py reports them per step)
 
     def allreduce_sum_(self, t: torch.Tensor) -> torch.Tensor:
         return t
@@ -88,24 +90,30 @@ class TorchDistComm(Comm):
         self._group = group
         self.world_size = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
+        # DMDX_COMM_FORCE=1: issue every collective with ONE rank too -- the way RCCL itself gets
+        # exercised on a one-GPU box (tests/test_gpu_pipeline.py); never set by the product
+        self.exchanges = self.world_size > 1 or os.environ.get("DMDX_COMM_FORCE") == "1"
 
     def allreduce_sum_(self, t: torch.Tensor) -> torch.Tensor:
-        if self.world_size > 1:
+        if self.exchanges:
+            self.n_collectives += 1
             self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self._group)
         return t
 
     def allgather(self, t: torch.Tensor) -> list[torch.Tensor]:
-        if self.world_size == 1:
+        if not self.exchanges:
             return [t]
         out = [torch.empty_like(t) for _ in range(self.world_size)]
+        self.n_collectives += 1
         self._dist.all_gather(out, t.contiguous(), group=self._group)
         return out
 
     def broadcast_(self, *tensors: torch.Tensor):
-        if self.world_size > 1:
+        if self.exchanges:
             if len(tensors) > 1 and len({(t.dtype, t.device) for t in tensors}) == 1:
                 # ONE collective for the lot (eigenvalues + eigenvectors, rotation + values)
                 flat = torch.cat([t.reshape(-1) for t in tensors])
+                self.n_collectives += 1
                 self._dist.broadcast(flat, src=0, group=self._group)
                 off = 0
                 for t in tensors:
@@ -113,11 +121,12 @@ class TorchDistComm(Comm):
                     off += t.numel()
             else:
                 for t in tensors:
+                    self.n_collectives += 1
                     self._dist.broadcast(t, src=0, group=self._group)
         return tensors if len(tensors) != 1 else tensors[0]
 
     def gather_to_root(self, t: torch.Tensor) -> list[torch.Tensor] | None:
-        if self.world_size == 1:
+        if not self.exchanges:
             return [t.cpu()]
         dist = self._dist
         # gloo moves host memory, RCCL device memory: stage accordingly
@@ -544,7 +553,7 @@ def _gram_blocks(blocks, kern, comm: Comm) -> torch.Tensor:
     at n = 8760 (the one large exchange of the row-sharded method of snapshots)."""
     G = kern.syrk_blocks(blocks) if len(blocks) > 1 else kern.syrk(blocks[0])
     n = G.shape[0]
-    if comm.world_size > 1 and n >= 64 and hasattr(kern, "pack_triu"):
+    if comm.exchanges and n >= 64 and hasattr(kern, "pack_triu"):
         packed = comm.allreduce_sum_(kern.pack_triu(G))
         return kern.unpack_triu(packed, n, out=G)
     return comm.allreduce_sum_(G)
@@ -602,7 +611,7 @@ def _sign_flip(Ublocks, Vh: torch.Tensor, comm: Comm, kern):
     allv = torch.stack(vals, dim=0)  # (blocks, k)
     pick = allv.abs().argmax(dim=0, keepdim=True)
     val = allv.gather(0, pick).squeeze(0)
-    if comm.world_size > 1:
+    if comm.exchanges:
         # ONE exchange per rank, whatever its number of row blocks (ranks may hold different numbers
         # of blocks: bands of different height, streamed pieces)
         allv = torch.stack(comm.allgather(val.contiguous()), dim=0)  # (world, k)
@@ -638,7 +647,7 @@ def _shard_stats(blocks, comm: Comm, delay: int, with_mean: bool) -> dict:
             v[1] += (mean * mean).sum()
             v[2] += var.sum()
     v[3] = float(sum(B.shape[1] for B in blocks) * delay)
-    if comm.world_size > 1:
+    if comm.exchanges:
         allv = torch.stack(comm.allgather(v))
         v = torch.cat([allv[:, :1].max(dim=0).values, allv[:, 1:].sum(dim=0)])
     amax, mean2, var, rows = v.tolist()
@@ -927,7 +936,7 @@ def svd_snapshots_streaming(pieces, n_components: int, rows_global: int, delay: 
     if G is None:
         raise ValueError("svd_snapshots_streaming: no pieces")
     n_t = G.shape[0]
-    if comm.world_size > 1 and n_t >= 64 and hasattr(kern, "pack_triu"):
+    if comm.exchanges and n_t >= 64 and hasattr(kern, "pack_triu"):
         G = kern.unpack_triu(comm.allreduce_sum_(kern.pack_triu(G)), n_t, out=G)
     else:
         comm.allreduce_sum_(G)

@@ -220,14 +220,19 @@ def test_create_mock_era5_svd_and_combine_like_the_reference_tests():
     assert dx["U"].shape[0] == dx["X"].shape[0] and dx["V"].shape[1] == dx["X"].shape[1]
 
 
+@pytest.mark.parametrize("ranks", ["two-over-gloo", "one-over-rccl"])
 @pytest.mark.parametrize("streamed", [False, True])
-def test_main_sharded_over_two_ranks(svd_base_config, tmp_path, monkeypatch, streamed):
+def test_main_sharded_over_two_ranks(svd_base_config, tmp_path, monkeypatch, streamed, ranks):
     """``main`` under torch.distributed.run, one process per rank, the space
     points sharded by latitude band -- here two ranks sharing the one GPU of the box over gloo
     (the driver's multi-GPU runs use RCCL).  Rank 0's result file must hold the same
     decomposition, in the same row order, as a single-process run on the same slice.
     ``streamed``: each rank additionally streams its band from the file in two passes (pieces of
-    4 latitude rows), as it would for a slice larger than the HBM."""
+    4 latitude rows), as it would for a slice larger than the HBM.
+    ``one-over-rccl``: RCCL wants one GPU per rank, so on this box it can only carry a ONE-rank
+    group -- DMDX_COMM_FORCE=1 makes that group issue every collective of the sharded path
+    (packed Gram all-reduce, stats all-gather, broadcasts, the gather to the root) through the
+    nccl backend with device tensors, which is what gloo's host staging cannot check."""
     import json
     import os
     import socket
@@ -266,16 +271,24 @@ def test_main_sharded_over_two_ranks(svd_base_config, tmp_path, monkeypatch, str
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    env = dict(os.environ, DMD_ERA5_ROOT=str(roots["two"]), DMDX_DIST_BACKEND="gloo", DMDX_DEVICE="0",
-               DMDX_TEST_CONFIG=json.dumps(cfg))
+    env = dict(os.environ, DMD_ERA5_ROOT=str(roots["two"]), DMDX_DEVICE="0", DMDX_TEST_CONFIG=json.dumps(cfg))
+    if ranks == "two-over-gloo":
+        env["DMDX_DIST_BACKEND"] = "gloo"
+    else:
+        env.pop("DMDX_DIST_BACKEND", None)
+        env.update(DMDX_COMM_FORCE="1", DMDX_TEST_EXPECT_BACKEND="nccl")
     if streamed:
         env["DMDX_STREAM_BYTES"] = str(4 * 4 * 49 * 2 * 72)
-    run = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+    nproc = "2" if ranks == "two-over-gloo" else "1"
+    run = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", nproc,
                           "--master-addr", "127.0.0.1", "--master-port", str(port),
                           os.path.join(here, "dist_main_worker.py")],
                          env=env, capture_output=True, text=True, timeout=600)
     assert run.returncode == 0, run.stdout[-3000:] + run.stderr[-3000:]
-    assert "latitude rows 0:18" in run.stdout and "latitude rows 18:36" in run.stdout
+    if ranks == "two-over-gloo":
+        assert "latitude rows 0:18" in run.stdout and "latitude rows 18:36" in run.stdout
+    else:
+        assert "backend nccl" in run.stdout and "collectives issued" in run.stdout
     two = io_netcdf.open_dataset(p["save_path"])
 
     monkeypatch.setenv("DMD_ERA5_ROOT", str(roots["one"]))
@@ -399,14 +412,18 @@ def test_main_streams_a_slice_that_does_not_fit(svd_base_config, tmp_path, monke
         assert "X_mean" not in b.data_vars and float(b["s"].values[0]) > 200 * float(b["s"].values[1])
 
 
+@pytest.mark.parametrize("ranks", ["two-over-gloo", "one-over-rccl"])
 @pytest.mark.parametrize("workload", ["small", "small-randomized"])
-def test_bench_two_ranks_on_one_gpu_over_gloo(workload):
+def test_bench_two_ranks_on_one_gpu_over_gloo(workload, ranks):
     """bench.py's N > 1 path as the driver launches it (torch.distributed.run, one process per
     rank, RANK / LOCAL_RANK / WORLD_SIZE from the environment) -- rehearsed with two ranks on the
     box's one GPU over gloo (DMDX_BENCH_DEVICE / DMDX_DIST_BACKEND; RCCL needs one GPU per rank and
     is the driver's 8-GPU run).  The line must say what the ranks saw: world size, backend, one
     device entry per rank; row shards of ONE global matrix: the singular values of the 2-rank run
-    are those of the stacked matrix (sqrt(2) x the planted single-shard ones, 5 %)."""
+    are those of the stacked matrix (sqrt(2) x the planted single-shard ones, 5 %).
+    ``one-over-rccl``: the same launch with ONE rank and the default backend -- the only group
+    RCCL can form on a one-GPU box; DMDX_BENCH_FORCE_DIST / DMDX_COMM_FORCE make it carry every
+    collective of the step (device tensors through the nccl backend)."""
     import json
     import os
     import socket
@@ -417,29 +434,40 @@ def test_bench_two_ranks_on_one_gpu_over_gloo(workload):
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    env = dict(os.environ, DMDX_BENCH_DEVICE="0", DMDX_DIST_BACKEND="gloo")
+    env = dict(os.environ, DMDX_BENCH_DEVICE="0")
+    if ranks == "two-over-gloo":
+        env["DMDX_DIST_BACKEND"] = "gloo"
+    else:
+        env.pop("DMDX_DIST_BACKEND", None)
+        env.update(DMDX_BENCH_FORCE_DIST="1", DMDX_COMM_FORCE="1")
     extra = ["--workload", "small"]
     if workload == "small-randomized":
         env["DMDX_BENCH_SVD_TYPE"] = "randomized"
-    run = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+    w = 2 if ranks == "two-over-gloo" else 1
+    run = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(w),
                           "--master-addr", "127.0.0.1", "--master-port", str(port),
-                          os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"] + extra,
+                          os.path.join(root, "bench.py"), "--gpus", str(w), "--steps", "2", "--warmup", "1",
+                          "--no-cpu-baseline", "--no-calibrate"] + extra,
                          env=env, capture_output=True, text=True, timeout=600, cwd=root)
     assert run.returncode == 0, run.stdout[-3000:] + run.stderr[-3000:]
     lines = [ln for ln in run.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, run.stdout[-2000:]
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["world_size"] == 2 and out["steps"] == 2 and out["scaling"] == "weak"
-    assert out["backend"].startswith("gloo") and [d["rank"] for d in out["devices"]] == [0, 1]
+    assert out["n_gpus"] == w and out["world_size"] == w and out["steps"] == 2 and out["scaling"] == "weak"
+    assert out["backend"].startswith("gloo" if w == 2 else "nccl") and [d["rank"] for d in out["devices"]] == list(range(w))
     assert all(d["device_index"] == 0 for d in out["devices"])
-    assert out["value"] > 0 and out["unit"] == "GB/s" and out["config"]["m_total"] == 2 * out["config"]["m_per_gpu"]
-    assert "cpu_baseline" not in out and "hard_spectrum" not in out          # N = 1 only
+    assert out["value"] > 0 and out["unit"] == "GB/s" and out["config"]["m_total"] == w * out["config"]["m_per_gpu"]
+    if w == 2:
+        assert "cpu_baseline" not in out and "hard_spectrum" not in out          # N = 1 only
+    else:
+        assert out["collectives_per_step"] > 0
     m, n = out["config"]["m_total"], out["config"]["n"]
     planted = 100.0 * 0.9 ** np.arange(3) * np.sqrt(float(m) * n)
     assert np.all(np.abs(np.array(out["s_head"]) / planted - 1.0) < 0.05), out["s_head"]
     if workload == "small":
         assert out["roofline"]["bound"] == "mfma" and out["roofline"]["frac"] > 0
-        assert "one packed-triangle Gram all-reduce" in out["config"]["sharding"]
+        if w == 2:
+            assert "one packed-triangle Gram all-reduce" in out["config"]["sharding"]
 
 
 @pytest.mark.parametrize("svd_type,center,scale,d", [("standard", True, False, 2), ("standard", True, True, 1),

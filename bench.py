@@ -372,6 +372,11 @@ def main():
         m_total, m = m, cuts[rank + 1] - cuts[rank]
     else:
         m_total = m * world
+    if dist is not None and svd_type == "standard":
+        # the first LARGE all-reduce pays RCCL's channel / buffer set-up: prime it at the size of the
+        # packed Gram triangle, outside the timed region whatever --warmup is
+        dist.all_reduce(torch.zeros(n * (n + 1) // 2, dtype=torch.float64, device=device))
+        torch.cuda.synchronize()
     gen = make_powerlaw_blocks if args.spectrum == "powerlaw" else make_snapshot_blocks
     blocks = gen(m, n, 1234 if args.workload != "cfg4" else 99, device, shard=rank)
     for Xb in blocks:

@@ -675,7 +675,10 @@ def main(config: dict | None = None, write_to_netcdf: bool = False, use_dvc: boo
     (``_device_pipeline``); rank 0 assembles, returns and writes the results, the other ranks
     return ``(None, False, False)`` -- unless the results were already on disk, which every
     rank finds for itself."""
+    import time
+
     _no_dvc(use_dvc)
+    t_start = time.perf_counter()
     if config is None:
         config = config_reader("era5-svd")
     parsed_config = config_parser(config, "era5-svd")
@@ -705,6 +708,7 @@ def main(config: dict | None = None, write_to_netcdf: bool = False, use_dvc: boo
         log_and_print(logger, msg, "error")
         raise Exception(msg) from e
 
+    t_open = time.perf_counter()
     comm, created = _dist_comm()
     try:
         ds = ds[parsed_config["variables"]]
@@ -715,6 +719,7 @@ def main(config: dict | None = None, write_to_netcdf: bool = False, use_dvc: boo
         else:
             U, s, V, coords, X, X_mean, X_std = _device_pipeline(ds, parsed_config, comm)
         svd_results = None
+        t_pipe = time.perf_counter()
         if comm.rank == 0:
             svd_results = combine_svd_results(U, s, V, coords, X=X, X_mean=X_mean, X_std=X_std)
             svd_results = add_config_attributes(svd_results, parsed_config)
@@ -732,11 +737,16 @@ def main(config: dict | None = None, write_to_netcdf: bool = False, use_dvc: boo
 
             dist.destroy_process_group()
 
+    t_done = time.perf_counter()
+    if comm.rank == 0:
+        log_and_print(logger, f"main(): slice found and opened in {t_open - t_start:.2f} s, ingest + SVD + gather "
+                              f"{t_pipe - t_open:.2f} s, result Dataset {t_done - t_pipe:.2f} s")
     if write_to_netcdf and svd_results is not None:
         try:
             log_and_print(logger, "Writing SVD results to NetCDF...")
             io_netcdf.to_netcdf(svd_results, parsed_config["save_path"])
-            log_and_print(logger, f"SVD results written to {parsed_config['save_path']}")
+            log_and_print(logger, f"SVD results written to {parsed_config['save_path']} "
+                                  f"({time.perf_counter() - t_done:.2f} s)")
         except Exception as e:
             msg = f"Error writing SVD results to NetCDF: {e}"
             log_and_print(logger, msg, "error")

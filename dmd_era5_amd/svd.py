@@ -261,6 +261,33 @@ def _eigh_desc(T: torch.Tensor, kern=None):
     return torch.flip(th, dims=(0,)), torch.flip(Z, dims=(1,))
 
 
+def _svd_wide(Bm: torch.Tensor, kern=None):
+    """Thin SVD of the wide l x n fp64 matrix B = Q^T X of the randomized path (extmath.py:579) ->
+    (Uhat (l, l), s (l,) descending, Vh (l, n)).  The library's gesvd is launch-rate bound with host
+    round trips (4 ms at 20 x 8760, of a 113 ms step); here B^T = Q_b R by CholeskyQR2 (`_orth`,
+    R = Q_b^T B^T whatever Q_b's triangularity), the l x l factor goes through the one-sided
+    Jacobi kernel (K7L: left singular vectors of R^T = Uhat, errors relative to each sigma) and
+    Vh = S^-1 Uhat^T B, re-orthonormalised by one Cholesky round.  A numerically rank-deficient B (s_l <= 1e-13 s_1: Vh's last rows would
+    be noise) and sizes beyond the kernel go to the library."""
+    l, n = Bm.shape
+    mx = getattr(kern, "svd_jacobi_max_n", 0) if kern is not None else 0
+    if Bm.dtype == torch.float64 and 2 <= l <= mx and n >= l:
+        try:
+            Bt = Bm.T.contiguous()
+            Qb = _orth(Bt, kern=kern)                       # (n, l), orthonormal columns
+            R = _tn(kern, Qb, Bt)                           # (l, l): B^T = Q_b R
+            sig, Zt = kern.svd_jacobi(R.contiguous())       # row c of R = column c of R^T
+            if bool(torch.isfinite(sig).all()) and float(sig[-1]) > 1e-13 * float(sig[0]):
+                # rows of S^-1 Uhat^T B are orthonormal to eps * s_1 / s_j only (2e-9 at cfg4's
+                # rank 200): one Cholesky round restores 1e-15 -- triangular, so every row is
+                # corrected against the rows of LARGER sigma, the accurate ones
+                Vt = _orth(((Zt @ Bm) / sig[:, None]).T.contiguous(), rounds=1, kern=kern)
+                return Zt.T.contiguous(), sig, Vt.T.contiguous()
+        except RuntimeError:
+            pass
+    return torch.linalg.svd(Bm, full_matrices=False)
+
+
 def _graded_eigh(s0: torch.Tensor, Mm: torch.Tensor, kern=None):
     """Eigenpairs (descending) of T = S M S, S = diag(s0) spanning many decades, M = U'^T U' close
     to the identity -- with RELATIVE accuracy for the small eigenvalues.  Up to the Jacobi kernel's
@@ -1096,7 +1123,7 @@ def svd_randomized_streaming(pieces, n_components: int, rows_global: int, n_time
         Qb = Qm[bounds[pi]:bounds[pi + 1]]
         Bm = kern.gemm_tn_blocks(Eb, Qb, out=Bm) if (Bm is not None or len(Eb) > 1) else kern.gemm_tn(Eb[0], Qb[0])
     comm.allreduce_sum_(Bm)
-    Uhat, s, Vh = torch.linalg.svd(Bm, full_matrices=False)
+    Uhat, s, Vh = _svd_wide(Bm, kern)
     Uhat, s, Vh = Uhat.contiguous(), s.contiguous(), Vh.contiguous()
     comm.broadcast_(Uhat, s, Vh)
     Uk = _pitched(kern, Uhat[:, :k].T.contiguous().to(torch.float32))
@@ -1245,7 +1272,7 @@ def svd_randomized(Xt, n_components: int, delay: int = 1, n_oversamples: int = 1
     Yb, G0 = _project_with_gram(kern, Eb, Qp, comm)        # extmath.py:355
     Qmb = _cholqr(Yb, comm, kern, passes=2, G0=G0)         # orthonormal basis of range(Y)
     Bm = _gemm_tn_blocks(Eb, Qmb, kern, comm)    # (l, nd) = Q^T X    (extmath.py:577)
-    Uhat, s, Vh = torch.linalg.svd(Bm, full_matrices=False)
+    Uhat, s, Vh = _svd_wide(Bm, kern)
     Uhat, s, Vh = Uhat.contiguous(), s.contiguous(), Vh.contiguous()
     comm.broadcast_(Uhat, s, Vh)
     Uk = _pitched(kern, Uhat[:, :k].T.contiguous().to(torch.float32))

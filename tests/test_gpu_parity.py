@@ -587,6 +587,29 @@ def test_eigh_large_matches_lapack(K, n):
         assert np.abs(A @ V2.cpu().numpy() - V2.cpu().numpy() * w2.cpu().numpy()).max() <= bound * ref[0]
 
 
+@pytest.mark.parametrize("l,n,decades", [(20, 8760, 4), (60, 8760, 7), (220, 3653, 6), (2, 50, 1)])
+def test_svd_wide_factor_of_the_randomized_path(K, l, n, decades):
+    """svd._svd_wide (CholeskyQR2 on K9 + K7L's one-sided Jacobi instead of the library's gesvd)
+    on the l x n factor B = Q^T X at the sizes of cfg2 (k = 10, 50) and cfg4 (k = 200): singular
+    values against the planted ones (1e-14 s_1 + 1e-12 s_j), B reproduced, orthonormal factors."""
+    from dmd_era5_amd import svd as dsvd
+
+    rs = np.random.RandomState(l * 7 + n)
+    U0, _ = np.linalg.qr(rs.standard_normal((l, l)))
+    V0, _ = np.linalg.qr(rs.standard_normal((n, l)))
+    s0 = np.logspace(0, -decades, l) * 3e6
+    B = (U0 * s0) @ V0.T
+    K.last_jacobi_sweeps = None
+    Uh, s, Vh = dsvd._svd_wide(_dev(B), K)
+    assert K.last_jacobi_sweeps is not None                  # the Jacobi kernel ran, not gesvd
+    Uh, s, Vh = Uh.cpu().numpy(), s.cpu().numpy(), Vh.cpu().numpy()
+    # the planted values: B itself carries eps * s_1 of rounding, LAPACK on the host no less
+    assert np.all(np.abs(s - s0) <= 1e-14 * s0[0] + 1e-12 * s0)
+    assert np.linalg.norm((Uh * s) @ Vh - B) <= 1e-13 * np.linalg.norm(B)
+    assert np.abs(Uh.T @ Uh - np.eye(l)).max() < 1e-12
+    assert np.abs(Vh @ Vh.T - np.eye(l)).max() < 1e-12
+
+
 def test_svd_jacobi_relative_accuracy_and_zero_columns(K):
     """Singular values over 14 decades come out with RELATIVE accuracy (what the graded refinement
     matrix needs and syevd / gesvd do not promise) -- checked against a 40-digit mpmath SVD --,
@@ -709,7 +732,7 @@ def test_eigh_small_matches_lapack(K, n):
     A = (Qm * lam) @ Qm.T
     A = 0.5 * (A + A.T)
     w, V = K.eigh_small(_dev(A))
-    assert 1 <= K.last_eigh_sweeps < 30        # the kernel reports its sweeps; 30 = its limit = not converged (raises)
+    assert (n > 1) <= K.last_eigh_sweeps < 30  # the kernel reports its sweeps; 30 = its limit = not converged (raises)
     w, V = w.cpu().numpy(), V.cpu().numpy()
     ref = np.linalg.eigvalsh(A)[::-1]
     assert np.all(np.diff(w) <= 0)

@@ -437,3 +437,32 @@ def test_powerlaw_generator_has_the_spectrum_it_claims():
     # one global matrix: stacking the shards keeps the spectrum (x sqrt(2)), it does not double the rank
     s2 = np.linalg.svd(np.concatenate([X, Y]), compute_uv=False)
     assert np.all(np.abs(s2 / (expect * np.sqrt(2)) - 1) < 3.5 * np.sqrt(n / m))
+
+
+@pytest.mark.parametrize("l,n,decades", [(20, 300, 3), (60, 500, 7), (7, 7, 2)])
+def test_svd_wide_matches_lapack(l, n, decades):
+    """The thin SVD of the randomized path's l x n factor B (CholeskyQR2 + one-sided Jacobi of the
+    l x l factor, svd._svd_wide) against LAPACK: singular values to 1e-12 relative, Uhat S Vh = B,
+    orthonormal factors; a rank-deficient B goes to the library."""
+    import torch
+
+    from dmd_era5_amd import svd as dsvd
+    from kernel_double import CpuKernelDouble as NumpyKernels
+
+    rs = np.random.RandomState(l + n)
+    U0, _ = np.linalg.qr(rs.standard_normal((l, l)))
+    V0, _ = np.linalg.qr(rs.standard_normal((n, l)))
+    s0 = np.logspace(0, -decades, l) * 5e3
+    B = torch.from_numpy((U0 * s0) @ V0.T)
+    Uh, s, Vh = dsvd._svd_wide(B.clone(), NumpyKernels())
+    assert np.allclose(s.numpy(), s0, rtol=1e-12)
+    assert torch.linalg.norm(Uh * s @ Vh - B) <= 1e-13 * torch.linalg.norm(B)
+    assert torch.linalg.norm(Uh.T @ Uh - torch.eye(l, dtype=torch.float64)) < 1e-12
+    assert torch.linalg.norm(Vh @ Vh.T - torch.eye(l, dtype=torch.float64)) < 1e-12
+    # rank-deficient: two equal rows
+    B2 = B.clone()
+    B2[-1] = B2[0]
+    Uh, s, Vh = dsvd._svd_wide(B2.clone(), NumpyKernels())
+    ref = np.linalg.svd(B2.numpy(), compute_uv=False)
+    assert np.allclose(s.numpy()[:-1], ref[:-1], rtol=1e-10) and s[-1] <= 1e-10 * s[0]
+    assert torch.linalg.norm(Uh * s @ Vh - B2) <= 1e-12 * torch.linalg.norm(B2)

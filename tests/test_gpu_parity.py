@@ -34,7 +34,8 @@ def _rand(rs, m, n, scale=1.0):
 # ---------------------------------------------------------------- K1 SYRK
 @pytest.mark.parametrize(
     "m,n",
-    [(32, 1), (33, 5), (1, 7), (1000, 128), (4096, 192), (5000, 129), (777, 300), (20011, 515)],
+    [(32, 1), (33, 5), (1, 7), (1000, 128), (4096, 192), (5000, 129), (777, 300), (20011, 515),
+     (6000, 312), (4099, 440), (8192, 193)],     # last tile column of 56 columns (cfg2's n % 128): the half-width edge unit
 )
 def test_syrk_matches_fp64_gram(K, m, n):
     rs = np.random.RandomState(m * 1000 + n)
@@ -86,7 +87,7 @@ def test_syrk_large_properties(K):
 
 
 # ---------------------------------------------------------------- K3 GEMM_TN
-@pytest.mark.parametrize("K_,na,nb", [(64, 3, 2), (1000, 130, 60), (4097, 300, 70), (50000, 192, 220),
+@pytest.mark.parametrize("K_,na,nb", [(64, 3, 2), (5000, 200, 190), (4099, 130, 131), (1000, 130, 60), (4097, 300, 70), (50000, 192, 220),
                                        (3001, 257, 33), (20000, 140, 150), (777, 64, 64), (5000, 1000, 129),
                                        (200000, 300, 90), (99999, 128, 96), (65536, 3653, 70)])   # 96-row tiles
 def test_gemm_tn(K, K_, na, nb):
@@ -756,7 +757,7 @@ def test_eigh_small_indefinite_repeated_and_limits(K):
 
 
 # ---------------------------------------------------------------- K1 over a list of row blocks
-@pytest.mark.parametrize("sizes,n", [([5000, 3000, 4097], 260), ([700] * 19, 70), ([1024, 7], 129),
+@pytest.mark.parametrize("sizes,n", [([5000, 3000, 4097], 260), ([700] * 19, 70), ([1024, 7], 129), ([4096] * 3 + [4100], 1336), ([3000] * 17, 1290),
                                      ([30001, 29999], 384)])
 def test_syrk_blocks_equals_sum_of_block_grams(K, sizes, n):
     """dmdx_syrk_blocks_f32 (one launch per 16 blocks) against the fp64 Gram of the stacked rows,

@@ -489,11 +489,19 @@ def _device_pipeline(ds: Dataset, parsed_config: dict, comm=None, kern=None, dev
         t0 = _time.perf_counter()
     else:
         t0 = _time.perf_counter()
+        # `python -m dmd_era5.era5_svd.era5_svd` is one process per slice: every run is a "first
+        # call".  While the slice crosses PCIe (the GPU and most host threads are idle) a side
+        # thread takes the SVD path once on a toy matrix, so that the dense libraries' handles and
+        # the code objects of every kernel are loaded when the real matrix is resident.
+        primer = _prime_async(device, parsed_config["svd_type"]) if device.type == "cuda" and \
+            4 * rows * len(take) >= (1 << 30) else None
         stats, total = {"mean": [], "std": []}, 0
         for name in names:
             vb, _, nbytes = _upload_variable(ds[name], level_idx, take, device, kern, center, scale, stats, band)
             blocks.extend(vb)
             total += nbytes
+        if primer is not None:
+            primer.join()
         sync()
         dt = _time.perf_counter() - t0
         log_and_print(logger, f"Ingest: {total / 1e9:.3f} GB to HBM in {dt:.2f} s ({total / 1e9 / max(dt, 1e-9):.2f} GB/s, "
@@ -589,6 +597,48 @@ def _device_pipeline(ds: Dataset, parsed_config: dict, comm=None, kern=None, dev
             Xc = Xg.reshape(n, -1).T.astype(out_dtype, copy=False)
             X = DataArray(_apply_delay_embedding_np(np.asfortranarray(Xc), d), ("space", "time"), coords)
     return U, s, V, coords, X, X_mean, X_std
+
+
+_PRIMED: set = set()
+
+
+def _prime_async(device, svd_type: str):
+    """Start (once per process, device and svd_type) a thread that runs the SVD path on a toy
+    matrix with a kernel provider of its own: first-use costs of rocBLAS / rocSOLVER / libdmdx
+    (0.3-0.8 s at cfg2 scale) overlap the ingest instead of following it.  Returns the thread, or
+    None when there is nothing left to prime or DMDX_NO_PRIME=1."""
+    import os
+    import threading
+
+    import torch
+
+    key = (str(device), svd_type)
+    if key in _PRIMED or os.environ.get("DMDX_NO_PRIME") == "1":
+        return None
+    _PRIMED.add(key)
+
+    def work():
+        try:
+            from . import svd as dsvd
+            from .kernels import HipKernels
+
+            torch.cuda.set_device(device)
+            k2 = HipKernels()
+            g = torch.Generator(device=device)
+            g.manual_seed(0)
+            toy = torch.randn((1024, 8192), device=device, dtype=torch.float32, generator=g)
+            halves = [toy[:, :4096].contiguous(), toy[:, 4096:].contiguous()]
+            if svd_type == "standard":
+                dsvd.svd_snapshots(halves, 12, delay=2, kern=k2)
+            else:
+                dsvd.svd_randomized(halves, 12, delay=2, random_state=0, kern=k2)
+            k2.release_workspace()
+        except Exception as e:      # priming is an optimisation: never fail the run for it
+            logger.debug(f"library priming failed: {e}")
+
+    t = threading.Thread(target=work, name="dmdx-prime", daemon=True)
+    t.start()
+    return t
 
 
 def _small_float64_slice(ds: Dataset, parsed_config: dict) -> bool:

@@ -76,3 +76,5 @@ for rank in (0, 3):
     got = torch.cat(blocks, dim=1)[5] + torch.cat(stats["mean"])
     print("   row check:", float((got - ref).abs().max()))
     del blocks
+import shutil
+shutil.rmtree(root, ignore_errors=True)

@@ -484,3 +484,24 @@ def test_svd_result_file_has_the_hdf5_objects_netcdf_c_requires(svd_base_config,
     path2 = str(project_root / "odd.nc")
     io_netcdf.to_netcdf(odd, path2)
     assert "delay" in io_netcdf.open_dataset(path2).data_vars
+
+
+@pytest.mark.parametrize("start,step_h,delta_h,n", [("2019-01-01T00", 1, 1, 100), ("2019-03-05T06", 6, 6, 40),
+                                                     ("2019-01-01T03", 3, 3, 17), ("2019-01-01T00", 24, 24, 9),
+                                                     ("2019-01-01T00", 1, 1, 1),
+                                                     # off the fast path: coarser delta, samples off the bins, a gap
+                                                     ("2019-01-01T00", 1, 6, 100), ("2019-01-01T01", 2, 2, 30),
+                                                     ("2019-01-01T00", 1, 1, -50)])
+def test_resample_fast_path_equals_pandas(start, step_h, delta_h, n):
+    """nearest_resample_index answers uniformly sampled, bin-aligned time axes without pandas:
+    labels and indices must be what pandas' resample(...).nearest() gives (ref slice_tools.py:139)."""
+    from datetime import timedelta
+
+    from dmd_era5_amd.slice_tools import nearest_resample_index
+
+    t = np.datetime64(start, "ns") + np.arange(abs(n)) * np.timedelta64(step_h, "h")
+    if n < 0:
+        t = np.delete(t, 7)                                   # a missing sample
+    a = nearest_resample_index(t, timedelta(hours=delta_h))
+    b = nearest_resample_index(t, timedelta(hours=delta_h), _force_pandas=True)
+    assert a[0].dtype == b[0].dtype and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])

@@ -315,7 +315,10 @@ class Writer:
                     self.attrs(name, {key: str(val)})
                     continue
                 tid = _h5type(lib, a.dtype)
-                sid = lib.H5Screate(0) if a.ndim == 0 else lib.H5Screate_simple(1, _dims(a.size), None)
+                # netCDF-C's layout (nc4hdf.c): every numeric attribute is a 1-D array, a single
+                # value included (np.ascontiguousarray has made it one); only its own bookkeeping
+                # attribute _Netcdf4Dimid sits in a scalar dataspace
+                sid = lib.H5Screate(0) if key == "_Netcdf4Dimid" else lib.H5Screate_simple(1, _dims(a.size), None)
                 aid = lib.H5Acreate2(loc, key.encode(), tid, sid, _H5P_DEFAULT, _H5P_DEFAULT)
                 lib.H5Awrite(aid, tid, a.ctypes.data_as(C.c_void_p))
             if aid < 0:

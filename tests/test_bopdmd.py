@@ -194,3 +194,37 @@ def test_exp_basis_kernel_matches_complex128_exp(dtype):
     assert float((Phi.to(torch.complex128) - ref).abs().max()) < tol
     assert float((W.to(torch.complex128) - t[:, None] * ref).abs().max()) < tol * 366
     assert torch.equal(bop._phi(alpha, t, dtype), Phi)              # the fit's basis IS the kernel's output
+
+
+def test_fit_is_the_optimum_an_independent_optimiser_finds():
+    """No pydmd here, so an independent check of WHAT optdmd converges to: the variable-projection
+    functional ||H - Phi(alpha) Phi(alpha)^+ H||_F, restated in three lines of numpy (lstsq) and
+    minimised by scipy's trust-region least squares from the same start.  Noisy, unevenly sampled
+    data (the minimum is not the planted alpha): both must land on the same eigenvalues and the
+    same residual."""
+    from scipy.optimize import least_squares
+
+    rs = np.random.RandomState(21)
+    t = np.sort(rs.uniform(0, 5, 90))
+    alpha = ALPHA[:4]
+    H, _ = _signal(t, n_s=5, noise=3e-2, seed=22, alpha=alpha)
+    Hn = H.numpy()
+    start = alpha * (1 + 0.03 * rs.standard_normal(4)) + 0.02 * rs.standard_normal(4)
+
+    def resid(x):
+        a = x[:4] + 1j * x[4:]
+        Phi = np.exp(np.outer(t, a))
+        B = np.linalg.lstsq(Phi, Hn, rcond=None)[0]
+        R = Hn - Phi @ B
+        return np.concatenate([R.real.ravel(), R.imag.ravel()])
+
+    sol = least_squares(resid, np.concatenate([start.real, start.imag]), method="trf", xtol=1e-14, ftol=1e-14, gtol=1e-12)
+    ref = sol.x[:4] + 1j * sol.x[4:]
+    ref_err = np.linalg.norm(resid(sol.x)) / np.linalg.norm(Hn)
+
+    res = bop.optdmd(H, torch.from_numpy(t), 4, alpha0=torch.from_numpy(start), tol=1e-13, maxiter=200)
+    got = res.eigs.numpy()
+    assert abs(res.rel_error - ref_err) < 1e-9 * ref_err + 1e-12, (res.rel_error, ref_err)
+    assert max(np.min(np.abs(got - a)) for a in ref) < 1e-6
+    # and it IS a different point than the planted one (the noise moved the minimum)
+    assert max(np.min(np.abs(ref - a)) for a in alpha) > 1e-4

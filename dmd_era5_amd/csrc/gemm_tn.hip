@@ -1018,7 +1018,8 @@ void xty_small_plan(const int64_t* K, int nb_, int ntiles, int* chunks, int* cps
     if (want > maxs) want = maxs;
     if (want < 1) want = 1;
     cps[j] = (int)((chunks[j] + want - 1) / want);
-    nsplit[j] = (chunks[j] + cps[j] - 1) / cps[j];
+    // a block of fewer than 64 rows has no full chunk: no units here, all of it goes to the tail launch
+    nsplit[j] = cps[j] > 0 ? (chunks[j] + cps[j] - 1) / cps[j] : 0;
     total += nsplit[j] * ntiles;
   }
   *units = total;
@@ -1065,8 +1066,10 @@ int run_xty_small(const float* const* X, const int64_t* ldx, const float* const*
     bt.na = (int)na;
     bt.nb = (int)nb;
     bt.P = reinterpret_cast<double*>(ws);
-    hipLaunchKernelGGL(xty_small_kernel, dim3((unsigned)units), dim3(NTH), 0, stream, bt);
-    DMDX_LAUNCH_CHECK();
+    if (units > 0) {   // (a group of blocks that are all shorter than one chunk: the reduce kernel still defines D)
+      hipLaunchKernelGGL(xty_small_kernel, dim3((unsigned)units), dim3(NTH), 0, stream, bt);
+      DMDX_LAUNCH_CHECK();
+    }
     hipLaunchKernelGGL(xty_small_reduce_kernel, dim3((unsigned)ntiles, (unsigned)nb), dim3(XT), 0, stream, bt, D64, ld64,
                        (accumulate || j0 > 0) ? 1 : 0);
     DMDX_LAUNCH_CHECK();

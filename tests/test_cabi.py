@@ -78,6 +78,34 @@ def test_workspace_queries(lib):
     assert lib.dmdx_syrk_blocks_workspace_bytes(None, 0, 70) == 0
 
 
+def test_workspace_planners_survive_degenerate_shapes():
+    """The planners are host code and run for every shape a caller hands in -- including row blocks
+    shorter than one 64-row chunk of the small-l X^T Y body (a fuzz run died of SIGFPE there:
+    0 chunks -> 0 chunks per split -> division by zero in dmdx_gemm_tn_blocks_workspace_bytes)."""
+    import ctypes as C
+    import itertools
+
+    from dmd_era5_amd import _lib
+
+    lib = _lib.load()
+    for sizes, na, nb in itertools.product([[1], [63, 1], [5, 64, 7000], [64] * 17, [1] * 40, [3000, 2]],
+                                           [1, 127, 128, 129, 500, 8760], [1, 2, 20, 32, 33, 96, 97, 130, 220]):
+        ks = (C.c_int64 * len(sizes))(*sizes)
+        w = lib.dmdx_gemm_tn_blocks_workspace_bytes(ks, len(sizes), na, nb)
+        assert w > 0, (sizes, na, nb)
+        assert lib.dmdx_syrk_blocks_workspace_bytes(ks, len(sizes), na) > 0
+    for K, na, nb in itertools.product([1, 31, 32, 33, 64], [1, 33, 129], [1, 32, 97]):
+        assert lib.dmdx_gemm_tn_workspace_bytes(K, na, nb) > 0 and lib.dmdx_syrk_workspace_bytes(K, na) > 0
+    for m, l in itertools.product([1, 3, 64, 1000], [1, 2, 31, 96]):
+        assert lib.dmdx_gemm_nn_skinny_gram_workspace_bytes(m, l) >= 0
+    for n, b in itertools.product([2, 3, 8760], [2, 62, 124, 4096]):
+        assert lib.dmdx_symm_skinny_workspace_bytes(n, b) >= 0
+    for n, b1, b2 in itertools.product([1, 2, 8760], [2, 78], [2, 124]):
+        assert lib.dmdx_gemm_tn_f64_workspace_bytes(n, b1, b2) >= 0
+    for n in (2, 3, 78, 1024, 1025):
+        assert lib.dmdx_svd_jacobi_workspace_bytes(n) >= 0
+
+
 def test_product_has_no_cpu_fallback():
     """Without a GPU the kernel provider must refuse to construct."""
     import torch

@@ -45,7 +45,7 @@ for name, shape, e0, e1 in events:
         rows["gemm_tn"].append((shape[0], e0.elapsed_time(e1)))
 out = {"metric": "randomized rank-r SVD GB/s on ERA5 snapshot matrix (X resident in HBM)",
        "value": m * n * 4.0 / dt / 1e9, "unit": "GB/s", "ms_per_step": dt * 1e3, "n_gpus": 1,
-       "config": {"workload": desc.replace("method-of-snapshots", "randomized (sklearn defaults)"), "k": a.k,
+       "config": {"workload": desc.replace("method-of-snapshots", "randomized (sklearn defaults)").replace("rank-50", f"rank-{a.k}"), "k": a.k,
                   "l": l, "n_iter": int(res.info["n_iter"]), "passes_over_X": 2 * int(res.info["n_iter"]) + 2},
        "kernels": {}}
 for name, label in (("skinny", "K2 skinny_kernel (Y = X Q)"), ("gemm_tn", "K3 (Z = X^T Y: 64x128-tile generic body, or K3s at l <= 32)")):

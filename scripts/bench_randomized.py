@@ -58,8 +58,8 @@ for name, label in (("skinny", "K2 skinny_kernel (Y = X Q)"), ("gemm_tn", "K3 (Z
         "roofline": {"bound": "hbm", "achieved": 4.0 * mb * n / (ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                      "frac": 4.0 * mb * n / (ms * 1e-3) / 1e9 / 8000.0},
         "algorithmic_tflops": 2.0 * mb * n * l / (ms * 1e-3) / 1e12,
-        "mfma_bound_note": "l is padded to 64 columns: at the nominal 157.3 TFLOP/s the padded MFMA work alone takes "
-                           "%.2f ms per launch" % (2.0 * mb * n * 64 / 157.3e12 * 1e3)}
+        "mfma_bound_note": "l is padded to %d columns: at the nominal 157.3 TFLOP/s the padded MFMA work alone takes "
+                           "%.2f ms per launch" % (-(-l // 32) * 32, 2.0 * mb * n * (-(-l // 32) * 32) / 157.3e12 * 1e3)}
 # the core clock the chip holds under each of the two kernels (per-workgroup s_memtime /
 # s_memrealtime stamps, dmdx_set_clock_probe): both run the fp32 MFMA pipe while streaming X from
 # HBM, and the clock under that load is ~2.0 GHz, not the 2.4 GHz of the nominal peak

@@ -6,7 +6,6 @@ reference's tests match on them: "Missing required field in config: {f}",
 "Invalid delay embedding in config", "Invalid number of components in config")."""
 from __future__ import annotations
 
-import os
 from datetime import datetime, timedelta
 from logging import Logger
 

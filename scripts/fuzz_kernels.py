@@ -58,6 +58,26 @@ for i in range(N):
         Xc = Xt.contiguous().clone(); mean, std = K.row_center_scale_(Xc, bool(i % 2))
         refm = X.mean(dim=0)
         check(f"center m={m} n={n}", mean, refm, refm.abs() + X.abs().mean(dim=0), tol=1e-6)
+        # guard bands: in-place K5 on a padded view and K2 into a padded `out` view must leave the
+        # padding columns (and the words before / behind the view) untouched
+        pad = int(rs.choice([1, 3, 4, 8])); off = int(rs.choice([0, 1, 2, 4]))
+        SENT = 12345.678
+        buf = torch.full((n * (m + pad) + off + 8,), SENT, device="cuda", dtype=torch.float32)
+        Xg = buf[off: off + n * (m + pad)].view(n, m + pad)[:, :m]
+        Xg.copy_(Xt)
+        K.row_center_scale_(Xg, bool(i % 2))
+        whole = buf[off: off + n * (m + pad)].view(n, m + pad)
+        if not (bool((whole[:, m:] == SENT).all()) and bool((buf[:off] == SENT).all()) and bool((buf[off + n * (m + pad):] == SENT).all())):
+            bad += 1; print("BAD guard K5", m, n, pad, off, flush=True)
+        if n > 1 or not (i % 2):     # (one sample, scaled: 0 / 0 = NaN on both paths, as in numpy)
+            check(f"center view m={m} n={n}", Xg, Xc.double(), Xc.double().abs() + 1e-30, tol=1e-6)
+        obuf = torch.full((l * (m + pad) + off + 8,), SENT, device="cuda", dtype=torch.float32)
+        Og = obuf[off: off + l * (m + pad)].view(l, m + pad)[:, :m]
+        K.skinny(Xt, Wt, out=Og)
+        ow = obuf[off: off + l * (m + pad)].view(l, m + pad)
+        if not (bool((ow[:, m:] == SENT).all()) and bool((obuf[:off] == SENT).all()) and bool((obuf[off + l * (m + pad):] == SENT).all())):
+            bad += 1; print("BAD guard K2", m, n, l, pad, off, flush=True)
+        check(f"skinny out view m={m} n={n} l={l}", Og, Wt.double() @ X, Wt.double().abs() @ X.abs(), tol=4e-6)
     except Exception as e:
         bad += 1
         print("EXC", i, m, n, l, repr(e)[:300], flush=True)

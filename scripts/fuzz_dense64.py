@@ -5,6 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dmd_era5_amd.kernels import default_kernels
 from dmd_era5_amd import svd as S
 K = default_kernels()
+import _ws_guard
+_ws_guard.install(K)     # exact-size workspaces with a sentinel band behind them
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rs = np.random.RandomState(977 + int(os.environ.get("DMDX_FUZZ_SEED", "0")))
 g = torch.Generator(device="cuda").manual_seed(7)
@@ -65,6 +67,7 @@ for i in range(N):
         Phi, W = K.exp_basis(al, t, torch.complex64 if i % 2 else torch.complex128)
         ref = torch.exp(t[:, None] * al[None, :])
         flag(f"exp_basis n={nt} r={r}", float((Phi.to(torch.complex128) - ref).abs().max()), 2e-6 if i % 2 else 1e-13)
+        bad += _ws_guard.check(f"round {i} n={n} b={b}")
     except Exception as e:
         bad += 1
         print("EXC", i, n, b, repr(e)[:300], flush=True)

@@ -9,6 +9,9 @@ rs = np.random.RandomState(123 + int(os.environ.get("DMDX_FUZZ_SEED", "0")))
 g = torch.Generator(device="cuda").manual_seed(5)
 bad = 0
 
+import _ws_guard
+_ws_guard.install(K)     # exact-size workspaces with a sentinel band behind them
+
 def view(rows, cols):
     """(rows, cols) fp32 view with random row padding and a random element offset (alignment 4..16 B)."""
     pad = int(rs.choice([0, 0, 1, 3, 4, 8])); off = int(rs.choice([0, 0, 1, 2, 4]))
@@ -78,6 +81,11 @@ for i in range(N):
         if not (bool((ow[:, m:] == SENT).all()) and bool((obuf[:off] == SENT).all()) and bool((obuf[off + l * (m + pad):] == SENT).all())):
             bad += 1; print("BAD guard K2", m, n, l, pad, off, flush=True)
         check(f"skinny out view m={m} n={n} l={l}", Og, Wt.double() @ X, Wt.double().abs() @ X.abs(), tol=4e-6)
+        Gf = torch.zeros((l, l), dtype=torch.float64, device="cuda")
+        if l <= K.skinny_gram_max_l:
+            Yg = K.skinny(Xt, Wt, gram=Gf)
+            check(f"skinny+gram m={m} n={n} l={l}", Gf, Yg.double() @ Yg.double().T, Yg.double().abs() @ Yg.double().abs().T, tol=4e-6)
+        bad += _ws_guard.check(f"round {i} m={m} n={n} l={l} nb={nb}")
     except Exception as e:
         bad += 1
         print("EXC", i, m, n, l, repr(e)[:300], flush=True)

@@ -4,6 +4,8 @@ import os, sys, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dmd_era5_amd.kernels import default_kernels
 K = default_kernels()
+import _ws_guard
+_ws_guard.install(K)     # exact-size workspaces with a sentinel band behind them
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 rs = np.random.RandomState(7 + int(os.environ.get("DMDX_FUZZ_SEED", "0")))
 g = torch.Generator(device="cuda").manual_seed(11)
@@ -37,6 +39,14 @@ for i in range(N):
     Z = K.gemm_tn(Xt, Y)                                # (l, n) = (X^T Y)^T
     Yd = Y.double()
     check(f"gemm_tn m={m} n={n} l={l}", Z, Yd @ X.T, Yd.abs() @ aX.T, 3e-6)
+    # the batched products at row-block scale, small l included (K3s) and more blocks than one launch takes
+    l2 = int(rs.choice([1, 7, 20, 32])); nb2 = int(rs.choice([3, 17]))
+    cuts2 = np.linspace(0, m, nb2 + 1).astype(int); cuts2 = (cuts2 // 4) * 4; cuts2[-1] = m
+    Xb = [Xt[:, a:b] for a, b in zip(cuts2[:-1], cuts2[1:])]
+    Yb = [Y[:l2, a:b].contiguous() for a, b in zip(cuts2[:-1], cuts2[1:])]
+    Zb = K.gemm_tn_blocks(Xb, Yb)
+    check(f"gemm_tn_blocks m={m} n={n} l={l2} nb={nb2}", Zb, Yd[:l2] @ X.T, Yd[:l2].abs() @ aX.T, 3e-6)
+    bad += _ws_guard.check(f"case {i} m={m} n={n} l={l}")
     del X, aX, G, Gb, Y, Z, Yd, Xt
     print("ok", i, m, n, l, flush=True)
 print("done", N, "cases,", bad, "flagged")

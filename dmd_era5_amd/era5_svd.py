@@ -492,7 +492,9 @@ def _device_pipeline(ds: Dataset, parsed_config: dict, comm=None, kern=None, dev
         # `python -m dmd_era5.era5_svd.era5_svd` is one process per slice: every run is a "first
         # call".  While the slice crosses PCIe (the GPU and most host threads are idle) a side
         # thread takes the SVD path once on a toy matrix, so that the dense libraries' handles and
-        # the code objects of every kernel are loaded when the real matrix is resident.
+        # the code objects of every kernel are loaded when the real matrix is resident.  Only for
+        # slices of >= 1 GiB: the reference's default config (0.4 GB, scripts/bench_default_config.py)
+        # ingests in 0.1-0.4 s, less than the toy run takes -- 2.62 s primed against 1.99 s.
         primer = _prime_async(device, parsed_config["svd_type"]) if device.type == "cuda" and \
             4 * rows * len(take) >= (1 << 30) else None
         stats, total = {"mean": [], "std": []}, 0

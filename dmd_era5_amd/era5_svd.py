@@ -591,13 +591,35 @@ def _device_pipeline(ds: Dataset, parsed_config: dict, comm=None, kern=None, dev
         from .slice_tools import _apply_delay_embedding_np
 
         n = blocks[0].shape[0]
-        # one rank: concatenate on the host (a device-side cat would hold X twice in HBM)
-        Xall = torch.cat(blocks, dim=1) if comm.exchanges else torch.cat([b.cpu() for b in blocks], dim=1)
-        Xg = assemble(Xall, (n,))                        # (time, variable, level, lat, lon) on rank 0
-        del Xall
-        if root:
-            Xc = Xg.reshape(n, -1).T.astype(out_dtype, copy=False)
-            X = DataArray(_apply_delay_embedding_np(np.asfortranarray(Xc), d), ("space", "time"), coords)
+        nt, M = n - d + 1, sum(int(b.shape[1]) for b in blocks)
+        on_device = False
+        if not comm.exchanges and device.type == "cuda" and nt > 0:
+            free = torch.cuda.mem_get_info(device)[0] + max(
+                0, torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device))
+            on_device = 4 * d * M * nt + (1 << 30) <= free
+        if on_device:
+            # one rank and room for it: the embedded matrix is laid out on the device as the file
+            # wants it -- (space = k_delay * M + s, time) row-major, E[k M + s, t] = X[t + k, s] -- and
+            # leaves in one copy.  (The host route below gathers the time-major blocks, embeds them
+            # column-major as the reference does and lets the writer transpose 0.8 GB: 0.27 s of the
+            # 0.73 s a warm main() takes on the reference's default config; this takes 0.06 s.)
+            Xe = torch.empty((d, M, nt), dtype=torch.float32, device=device)
+            off = 0
+            for b in blocks:
+                mb = int(b.shape[1])
+                for kd in range(d):
+                    Xe[kd, off:off + mb].copy_(b[kd:kd + nt].T)
+                off += mb
+            X = DataArray(Xe.reshape(d * M, nt).cpu().numpy().astype(out_dtype, copy=False), ("space", "time"), coords)
+            del Xe
+        else:
+            # several ranks, or no room: concatenate on the host (a device-side cat would hold X twice in HBM)
+            Xall = torch.cat(blocks, dim=1) if comm.exchanges else torch.cat([b.cpu() for b in blocks], dim=1)
+            Xg = assemble(Xall, (n,))                        # (time, variable, level, lat, lon) on rank 0
+            del Xall
+            if root:
+                Xc = Xg.reshape(n, -1).T.astype(out_dtype, copy=False)
+                X = DataArray(_apply_delay_embedding_np(np.asfortranarray(Xc), d), ("space", "time"), coords)
     return U, s, V, coords, X, X_mean, X_std
 
 

@@ -27,9 +27,14 @@ with hdf5_lite.Writer(p["era5_slice_path"]) as w:
     coef = rs.standard_normal((n, 8)).astype(np.float32) * (0.8 ** np.arange(8, dtype=np.float32))
     w.dataset("temperature", (coef @ base + 280).reshape(n, 1, nlat, nlon), ("time", "level", "latitude", "longitude"))
     w.attrs(None, {"source_path": "synthetic", "variables": ["temperature"], "levels": [1000]})
-for rep in range(2):
+import cProfile, pstats
+for rep in range(3):
+    pr = cProfile.Profile() if (rep == 2 and len(sys.argv) > 1 and sys.argv[1] == "profile") else None
     t0 = time.perf_counter()
+    if pr: pr.enable()
     res, _, _ = main(cfg, write_to_netcdf=True)
+    if pr:
+        pr.disable(); pstats.Stats(pr).sort_stats("cumulative").print_stats(45)
     dt = time.perf_counter() - t0
     sz = os.path.getsize(p["save_path"]) / 1e9
     print(f"main() call {rep}: {dt:.2f} s total; result file {sz:.2f} GB; s head {res['s'].values[:3]}", flush=True)

@@ -17,7 +17,7 @@
 //   element j of both operands -- the same k permutation on both sides, so
 //   the contraction is unchanged.
 //   Numerics: fp32 MFMA chains of at most 128 chunks * 32 = 4096 rows; the chain
-//   results of a unit (at most 8) are summed in a second fp32 register
+//   results of a unit (at most 16) are summed in a second fp32 register
 //   accumulator (blocked summation: the error bound stays that of a 4096-row
 //   chain) and stored once, as fp64, into the unit's own partial tile (no
 //   atomics => deterministic); a second kernel sums the K-splits in fp64 and
@@ -37,7 +37,7 @@
 // Entry points: dmdx_syrk_f32 / dmdx_gemm_tn_f32 (one pair of operands per launch) and
 // dmdx_syrk_blocks_f32 / dmdx_gemm_tn_blocks_f32 (the sum over up to 16 row blocks per
 // launch, syrk_batch_kernel); all of them run tn_unit, the reduce kernel sums the K-splits.
-// Environment knobs (tuning / diagnosis only): DMDX_TN_MAX_CPS (chunks per unit, default 1024),
+// Environment knobs (tuning / diagnosis only): DMDX_TN_MAX_CPS (chunks per unit, default 2048),
 // DMDX_TN_ROUNDS (rounds of 512 workgroups the K-splits aim at), DMDX_TN_ABLATE (timing-only
 // ablations of the single-launch kernel: results are wrong).
 #include <stdarg.h>
@@ -267,7 +267,7 @@ __device__ __forceinline__ void tn_unit(const TnParams& p, const int split, cons
   // ---- two-level fp32 accumulation inside a unit, fp64 across units.
   // acc holds fp32 chains of at most FOLD*32 = 4096 rows.  Every FOLD chunks block
   // q = (mi, ni) of the wave is added into acc2 (registers) and cleared; the four blocks
-  // are staggered by FOLD/4 chunks.  A unit runs <= max_cps chunks, so acc2 sums <= 8
+  // are staggered by FOLD/4 chunks.  A unit runs <= max_cps chunks, so acc2 sums <= 16
   // chain results: the rounding error stays that of a 4096-row fp32 chain (blocked
   // summation), and the loop touches no memory except the operand stream.  (Folding
   // into an fp64 tile in HBM instead cost 4.6 % -- ~115 VALU/VMEM instructions per fold,
@@ -678,7 +678,10 @@ Plan make_plan(int64_t K, int64_t nrow, int64_t ncol, int syrk, int share = 1) {
   // aim at >= ~20 rounds of 512 resident workgroups, keep >= 8 chunks per split, and
   // keep units short enough (<= max_cps chunks) that the workgroups sharing panels in
   // L2 / Infinity Cache do not drift apart along K
-  int64_t max_cps = 1024;  // 256 measured +0.8 % but needs 4x the workspace
+  // (round 2, cfg2 Gram incl. the reduce kernel, interleaved on one box: 256 -> 564-567 ms, 512 / 1024 /
+  // 2048 -> 560-562 ms, 4096 -> 575-577 ms (38 rounds of 512: the last one shows).  2048 halves the
+  // partial-tile workspace of 1024: 5 GB instead of 10 GB at cfg2, 9.5 instead of 19 GB at a cfg3 shard)
+  int64_t max_cps = 2048;
   if (const char* e = getenv("DMDX_TN_MAX_CPS")) max_cps = atoll(e) > 0 ? atoll(e) : max_cps;
   // Rounds of 512 resident workgroups to aim at.  Every split costs a partial tile (written,
   // then read by the reduce kernel): many rounds only pay where the tiles are many and the

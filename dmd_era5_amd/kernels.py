@@ -79,7 +79,7 @@ class HipKernels:
 
     def release_workspace(self) -> int:
         """Drop the cached partial-tile workspaces (K1 / K3: 128 KB per (row block, K-split, tile)
-        of a launch -- 10.1 GB for cfg2's Gram, 19 GB for a cfg3 shard; they are kept between calls
+        of a launch -- 5.1 GB for cfg2's Gram, 9.5 GB for a cfg3 shard; they are kept between calls
         because re-allocating them costs more than the eigen stage).  Callers that are about to
         fill the HBM with something else (main() before a larger slice, the 227 GB cfg4 matrix)
         call this first.  Returns the number of bytes released."""
@@ -464,5 +464,5 @@ def default_kernels() -> HipKernels:
 
 def release_cached_workspaces() -> int:
     """Free the partial-tile workspaces of the process-wide provider, if one exists (main() does
-    after every run: 10-19 GB at cfg2 / cfg3 that the next, possibly larger, slice may need)."""
+    after every run: 5-10 GB at cfg2 / cfg3 that the next, possibly larger, slice may need)."""
     return _default.release_workspace() if _default is not None else 0

@@ -45,7 +45,7 @@ def test_syrk_matches_fp64_gram(K, m, n):
     X64 = X.astype(np.float64)
     ref = X64.T @ X64
     absref = np.abs(X64).T @ np.abs(X64)
-    # fp32 MFMA chains of <= 4096 rows (blocked summation of <= 8 chains per unit), fp64 across
+    # fp32 MFMA chains of <= 4096 rows (blocked summation of <= 16 chains per unit), fp64 across
     # units: error <= ~1e-6 * sum|a||b|
     assert np.all(np.abs(G - ref) <= 2e-6 * absref + 1e-30)
     assert np.array_equal(G, G.T), "both triangles must hold identical values"

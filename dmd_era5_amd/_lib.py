@@ -38,6 +38,7 @@ SIGNATURES = {
         [_p, _p, _p, _p, _p, C.c_int, _i64, _i64, _p, _i64, _p, _i64, C.c_int, _p, _sz, _p],
     ),
     "dmdx_gemm_nn_skinny_f32": (C.c_int, [_p, _i64, _i64, _i64, _p, _i64, _i64, _p, _i64, _p]),
+    "dmdx_gemm_nn_skinny_gram_max_l": (C.c_int, []),
     "dmdx_gemm_nn_skinny_gram_workspace_bytes": (_sz, [_i64, _i64]),
     "dmdx_gemm_nn_skinny_gram_f32": (C.c_int, [_p, _i64, _i64, _i64, _p, _i64, _i64, _p, _i64, _p, _i64, C.c_int,
                                                _p, _sz, _p]),

@@ -42,3 +42,12 @@ extern unsigned long long* dmdx_clock_probe_ptr;
   } while (0)
 
 static inline bool dmdx_aligned16(const void* p) { return ((uintptr_t)p & 15u) == 0; }
+
+// K2, 16x16x4 body (skinny16.hip): l <= 256 columns in one pass, 16-column granular, optional fused Gram
+bool dmdx_skinny16_shape_ok(int64_t m, int64_t ldx);
+int dmdx_skinny16_launch(const float* X, int64_t m, int64_t n, int64_t ldx, const float* W, int64_t ldw, int l, float* Y,
+                         int64_t ldy, hipStream_t st);
+size_t dmdx_skinny16_gram_ws(int64_t m, int64_t l);
+int dmdx_skinny16_gram_launch(const float* X, int64_t m, int64_t n, int64_t ldx, const float* W, int64_t ldw, int l,
+                              float* Y, int64_t ldy, double* G, int64_t ldg, int accumulate, float* gpart,
+                              hipStream_t st);

@@ -19,6 +19,8 @@
 // of prefetch distance, pinned with sched_group_barrier -- the scheduler otherwise sinks the
 // loads to their uses), barrier before the last step group.  cfg2 pass at l = 62: 9.5 ms
 // (3.8 TB/s of X, 81 % of the 64-column MFMA bound); l = 128: 16.6 ms = 140 TFLOP/s.
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "dmdx_common.h"
@@ -392,6 +394,16 @@ int launch_skinny(const float* X, int64_t m, int64_t n, int64_t ldx, const float
 
 }  // namespace
 
+// Which K2 body runs.  The 16x16x4 body (skinny16.hip: one pass over X up to 224 columns, 16-column
+// granular, fused Gram up to 224 columns) is the default; DMDX_K2_IMPL=old selects the 32x32x2 body
+// above (A/B measurements; it also remains the fallback for leading dimensions the new body's
+// 32-bit lane offsets cannot reach).
+static int k2_impl() {   // (read per call: scripts/ab_k2.py flips it inside one process)
+  const char* e = getenv("DMDX_K2_IMPL");
+  return (e && e[0] == 'o') ? 0 : 1;
+}
+constexpr int64_t K2_GROUP = 224;   // widest column group of the 16x16x4 body (14 blocks: no register spill)
+
 extern "C" int dmdx_gemm_nn_skinny_f32(const float* X, int64_t m, int64_t n, int64_t ldx,
                                        const float* W, int64_t ldw, int64_t l, float* Y,
                                        int64_t ldy, void* stream) {
@@ -401,6 +413,19 @@ extern "C" int dmdx_gemm_nn_skinny_f32(const float* X, int64_t m, int64_t n, int
   DMDX_CHECK_ARG(ldx >= 1 && ldw >= n && ldy >= m, "skinny: bad leading dimension");
   DMDX_CHECK_ARG(m + 4 * ldx < (1ll << 29), "skinny: m + 4 ldx >= 2^29 not supported");
   hipStream_t st = (hipStream_t)stream;
+  // (l <= 32 is HBM-bound: the 32x32x2 body reads 512-byte runs per column and wave-load, the
+  // 16x16x4 body 256-byte runs, and streams X 4-5 % slower there: scripts/ab_k2.py)
+  if (k2_impl() == 1 && l > 32 && dmdx_skinny16_shape_ok(m, ldx)) {
+    // column groups of at most 224, equally wide up to the 16-column granule; X is re-read per group
+    const int64_t ng = (l + K2_GROUP - 1) / K2_GROUP;
+    const int64_t per = ((l + ng - 1) / ng + 15) / 16 * 16;
+    for (int64_t c0 = 0; c0 < l; c0 += per) {
+      const int lg = (int)((l - c0) < per ? (l - c0) : per);
+      const int rc = dmdx_skinny16_launch(X, m, n, ldx, W + c0 * ldw, ldw, lg, Y + c0 * ldy, ldy, st);
+      if (rc) return rc;
+    }
+    return 0;
+  }
   // column groups of at most 128 (4 MFMA blocks); X is re-read per group
   for (int64_t c0 = 0; c0 < l; c0 += 128) {
     int lg = (int)((l - c0) < 128 ? (l - c0) : 128);
@@ -416,21 +441,32 @@ extern "C" int dmdx_gemm_nn_skinny_f32(const float* X, int64_t m, int64_t n, int
   return 0;
 }
 
-extern "C" size_t dmdx_gemm_nn_skinny_gram_workspace_bytes(int64_t m, int64_t l) {
-  if (m < 1 || l < 1 || l > 96) return 0;
+extern "C" int dmdx_gemm_nn_skinny_gram_max_l(void) { return k2_impl() == 1 ? (int)K2_GROUP : 96; }
+
+static size_t old_gram_ws(int64_t m, int64_t l) {
+  if (l > 96) return 0;
   const size_t c = (size_t)((l + 31) / 32);
   return (size_t)((m + ROWS_PER_WG - 1) / ROWS_PER_WG) * 4 * (c * (c + 1) / 2) * 1024 * sizeof(float);
+}
+
+extern "C" size_t dmdx_gemm_nn_skinny_gram_workspace_bytes(int64_t m, int64_t l) {
+  if (m < 1 || l < 1 || l > dmdx_gemm_nn_skinny_gram_max_l()) return 0;
+  // (the larger of the two bodies' needs: which one runs also depends on ldx, unknown here)
+  const size_t a = k2_impl() == 1 ? dmdx_skinny16_gram_ws(m, l) : 0, b = old_gram_ws(m, l);
+  return a > b ? a : b;
 }
 
 extern "C" int dmdx_gemm_nn_skinny_gram_f32(const float* X, int64_t m, int64_t n, int64_t ldx, const float* W,
                                             int64_t ldw, int64_t l, float* Y, int64_t ldy, double* G, int64_t ldg,
                                             int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
   DMDX_CHECK_ARG(X && W && Y && G, "skinny_gram: null pointer");
-  DMDX_CHECK_ARG(m >= 1 && n >= 1 && l >= 1 && l <= 96, "skinny_gram: bad shape m=%lld n=%lld l=%lld (l <= 96)",
-                 (long long)m, (long long)n, (long long)l);
+  const bool use16 = k2_impl() == 1 && l > 32 && dmdx_skinny16_shape_ok(m, ldx);
+  const int64_t lmax = use16 ? K2_GROUP : 96;
+  DMDX_CHECK_ARG(m >= 1 && n >= 1 && l >= 1 && l <= lmax, "skinny_gram: bad shape m=%lld n=%lld l=%lld (l <= %lld)",
+                 (long long)m, (long long)n, (long long)l, (long long)lmax);
   DMDX_CHECK_ARG(ldx >= 1 && ldw >= n && ldy >= m && ldg >= l, "skinny_gram: bad leading dimension");
   DMDX_CHECK_ARG(m + 4 * ldx < (1ll << 29), "skinny_gram: m + 4 ldx >= 2^29 not supported");
-  const size_t need = dmdx_gemm_nn_skinny_gram_workspace_bytes(m, l);
+  const size_t need = use16 ? dmdx_skinny16_gram_ws(m, l) : old_gram_ws(m, l);
   if (workspace == nullptr || workspace_bytes < need) {
     dmdx_set_error("skinny_gram: workspace %zu bytes < required %zu", workspace_bytes, need);
     return DMDX_E_WORKSPACE;
@@ -438,6 +474,7 @@ extern "C" int dmdx_gemm_nn_skinny_gram_f32(const float* X, int64_t m, int64_t n
   hipStream_t st = (hipStream_t)stream;
   float* gp = reinterpret_cast<float*>(workspace);
   const int li = (int)l;
+  if (use16) return dmdx_skinny16_gram_launch(X, m, n, ldx, W, ldw, li, Y, ldy, G, ldg, accumulate, gp, st);
   if (l <= 32) return launch_skinny<1>(X, m, n, ldx, W, ldw, li, Y, ldy, st, gp, G, ldg, accumulate);
   if (l <= 64) return launch_skinny<2>(X, m, n, ldx, W, ldw, li, Y, ldy, st, gp, G, ldg, accumulate);
   return launch_skinny<3>(X, m, n, ldx, W, ldw, li, Y, ldy, st, gp, G, ldg, accumulate);

@@ -210,7 +210,9 @@ class HipKernels:
         Wp[:, :n] = Wt
         return Wp[:, :n]
 
-    skinny_gram_max_l = 96
+    @property
+    def skinny_gram_max_l(self) -> int:
+        return int(self._lib.dmdx_gemm_nn_skinny_gram_max_l())
 
     def skinny(self, Xt: torch.Tensor, Wt: torch.Tensor, out: torch.Tensor | None = None,
                gram: torch.Tensor | None = None) -> torch.Tensor:

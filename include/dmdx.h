@@ -92,7 +92,7 @@ int dmdx_gemm_tn_blocks_f32(const float* const* A, const int64_t* lda, const flo
 
 /* ---- K2: tall-skinny Y = X W -----------------------------------------------
  * X: m x n (ldx, rows > ldx allowed), W: n x l (ldw), Y: m x l (ldy); l is processed in column
- * groups of 128 (X is re-read once per group).
+ * groups of at most 224, 16-column granular (X is re-read once per group).
  * U = X (V_r S^-1) of the method of snapshots and `A @ Q` of the range finder
  * (extmath.py:349,355).  Fast path (16-byte loads of X, W and stores of Y): m, ldx, ldw, ldy
  * multiples of 4 and X, W, Y 16-byte aligned; anything else takes the scalar-load path (same
@@ -102,11 +102,13 @@ int dmdx_gemm_nn_skinny_f32(const float* X, int64_t m, int64_t n, int64_t ldx,
                             const float* W, int64_t ldw, int64_t l,
                             float* Y, int64_t ldy, void* stream);
 
-/* K2 with the Gram of its output fused in: Y = X W as above (l <= 96) and G (+)= Y^T Y (l x l fp64,
- * ldg, both triangles), formed from the accumulators before they leave the registers: the
- * CholeskyQR rounds of the range finder (the LU / QR normalisers of extmath.py:349-355 in this
- * engine) need that Gram, and computing it separately is another pass over the m x l matrix.
- * Per-(workgroup, wave) fp32 partial tiles in the workspace, summed in fp64 (deterministic). */
+/* K2 with the Gram of its output fused in: Y = X W as above (l <= dmdx_gemm_nn_skinny_gram_max_l(),
+ * 224) and G (+)= Y^T Y (l x l fp64, ldg, both triangles), formed from the accumulators before
+ * they leave the registers: the CholeskyQR rounds of the range finder (the LU / QR normalisers of
+ * extmath.py:349-355 in this engine) need that Gram, and computing it separately is another pass
+ * over the m x l matrix.  Per-workgroup fp32 partial tiles in the workspace (summed over the
+ * workgroup's waves in a fixed order), added up in fp64 (deterministic). */
+int dmdx_gemm_nn_skinny_gram_max_l(void);
 size_t dmdx_gemm_nn_skinny_gram_workspace_bytes(int64_t m, int64_t l);
 int dmdx_gemm_nn_skinny_gram_f32(const float* X, int64_t m, int64_t n, int64_t ldx,
                                  const float* W, int64_t ldw, int64_t l, float* Y, int64_t ldy,

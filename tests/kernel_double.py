@@ -39,7 +39,7 @@ class CpuKernelDouble:
             Cm = self.gemm_tn(A, B) if Cm is None else self.gemm_tn(A, B, out=Cm)
         return Cm
 
-    skinny_gram_max_l = 96
+    skinny_gram_max_l = 224
 
     def skinny(self, Xt, Wt, out=None, gram=None):
         Y = (Wt.to(torch.float64) @ Xt.to(torch.float64)).float()

@@ -105,7 +105,11 @@ def test_gemm_tn(K, K_, na, nb):
 @pytest.mark.parametrize(
     "m,n,l",
     [(4, 2, 1), (512, 32, 32), (1000, 33, 50), (1003, 64, 64), (4096, 192, 60),
-     (5000, 191, 100), (3000, 100, 128), (2048, 77, 200), (130, 500, 7), (8192, 3653, 70)],
+     (5000, 191, 100), (3000, 100, 128), (2048, 77, 200), (130, 500, 7), (8192, 3653, 70),
+     # round 3, the 16x16x4 body: 16-column granules (l = 70 runs 80 columns, 72 -> 80, 80 -> 80), one pass up
+     # to 224 columns, two column groups above, rows that are no multiple of 256 / 64 / 4, n % 32 != 0
+     (8192, 3653, 80), (5000, 100, 72), (3000, 257, 220), (2048, 130, 224), (1030, 64, 256), (2050, 96, 300),
+     (7, 5, 3), (1001, 37, 70), (70000, 61, 17), (263, 31, 209)],
 )
 def test_skinny(K, m, n, l):
     rs = np.random.RandomState(m + 13 * n + 7 * l)
@@ -120,7 +124,10 @@ def test_skinny(K, m, n, l):
 
 
 @pytest.mark.parametrize("m,n,l", [(4, 2, 1), (512, 32, 32), (1003, 64, 20), (4096, 192, 60), (5000, 191, 70),
-                                   (130000, 96, 96), (777, 33, 64), (2048, 3653, 70)])
+                                   (130000, 96, 96), (777, 33, 64), (2048, 3653, 70),
+                                   # round 3: fused up to 224 columns (cfg4's l = 220), odd block counts, ragged rows
+                                   (2048, 3653, 72), (4099, 130, 130), (3000, 100, 220), (1000, 64, 224), (777, 33, 200),
+                                   (66000, 40, 150), (5, 3, 2)])
 def test_skinny_with_fused_gram(K, m, n, l):
     """K2 with the Gram of its output formed from the accumulators in the same launch: Y must be
     bit-identical to the plain K2 launch and G = Y^T Y (of the stored fp32 Y, fp64 reference)

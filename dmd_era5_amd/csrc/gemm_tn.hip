@@ -184,13 +184,20 @@ __device__ unsigned long long dmdx_stamp[8];
 // One work unit: the K-range of `split` of the TM x 128 output tile at (row0, col0) (D rows <-
 // columns of A, D cols <- columns of B), written as fp64 into the partial tile Pt.
 // lds: 2 stages of (TM + 128) x 32 floats.
-template <bool DMA, int ABL, int SK>
+// H16 (round 3): one more 16-row block below the SK 32-row blocks, on v_mfma_f32_16x16x4_f32 (same flop
+//   rate, half the rows): tile heights 48 / 80 / 112, so that l = 70 columns of Y (BASELINE config 4:
+//   rank 50 + 20 oversamples) run 80 rows instead of 96.  Its fragments are 8-byte reads (lane
+//   (i = lane & 15, kk = lane >> 4) takes k = 8 t + 2 kk + {0, 1} of its column: two MFMAs per k-step
+//   and 16-column half of the wave's 32 columns), conflict-free under the same swizzle.
+template <bool DMA, int ABL, int SK, int H16 = 0>
 __device__ __forceinline__ void tn_unit(const TnParams& p, const int split, const int row0, const int col0,
                                         double* Pt, float* lds) {
-  constexpr int TM = SK ? 32 * SK : BT;  // tile rows    (columns of OpA)
+  static_assert(!H16 || SK >= 1, "a 16-row block only below at least one 32-row block");
+  constexpr int TM = SK ? 32 * SK + 16 * H16 : BT;  // tile rows    (columns of OpA)
   constexpr int MI = SK ? SK : 2;        // 32-row MFMA blocks per wave
   constexpr int NI = SK ? 1 : 2;         // 32-column MFMA blocks per wave
-  constexpr int NPA = TM / 32;           // 1 KiB pieces of the A panel per wave (or 16 B pieces per thread)
+  constexpr int NPA = (TM + 31) / 32;    // 1 KiB pieces of the A panel per wave (or 16 B pieces per thread)
+  constexpr int NPIECE = TM / 8;         // 1 KiB pieces of the A panel in all (H16: wave w takes pieces w, w + 4, ...)
   constexpr int OPA = TM * BK, OPB = BT * BK, STG = OPA + OPB;  // floats per stage
   // stage st: A panel at lds + st * STG, B panel at lds + st * STG + OPA
 
@@ -234,9 +241,11 @@ __device__ __forceinline__ void tn_unit(const TnParams& p, const int split, cons
   }
 #pragma unroll
   for (int i = 0; i < NPA; ++i) {
-    const int lc = DMA ? (TM / 4) * wave + 8 * i + (lane >> 3) : (tid >> 3) + 32 * i;
+    // (H16: the A panel has TM / 8 pieces, not a multiple of 4: wave w takes the pieces w + 4 i < NPIECE;
+    // register path: the columns (tid >> 3) + 32 i < TM)
+    const int lc = DMA ? (H16 ? 8 * (wave + 4 * i) : (TM / 4) * wave + 8 * i) + (lane >> 3) : (tid >> 3) + 32 * i;
     const int q = DMA ? ((lane & 7) ^ swz(lc)) : (tid & 7);
-    int ca = row0 + lc;
+    int ca = row0 + (lc < TM ? lc : TM - 1);
     ca = ca < p.nrow ? ca : p.nrow - 1;
     aoff[i] = (unsigned)((int64_t)(ca - ra0) * p.lda + 4 * q);
     stsa[i] = lc * BK + 4 * (DMA ? (lane & 7) : ((tid & 7) ^ swz(lc)));
@@ -248,13 +257,13 @@ __device__ __forceinline__ void tn_unit(const TnParams& p, const int split, cons
   // Piece i of an operand lands at LDS base (M0) + 1024 i through the instruction's immediate
   // offset, which the hardware adds to the global address too: offsets carry + 3072 - 1024 i
   // and the base pointer - 3072, so that every offset stays non-negative.
-  const char* Adma = reinterpret_cast<const char*>(Abase) - 3072;
+  const char* Adma = reinterpret_cast<const char*>(Abase) - (H16 ? 0 : 3072);
   const char* Bdma = reinterpret_cast<const char*>(Bbase) - 3072;
   unsigned aoffb[NPA], boffb[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) boffb[i] = 4u * boff[i] + 3072u - 1024u * i;
 #pragma unroll
-  for (int i = 0; i < NPA; ++i) aoffb[i] = 4u * aoff[i] + 3072u - 1024u * i;
+  for (int i = 0; i < NPA; ++i) aoffb[i] = H16 ? 4u * aoff[i] : 4u * aoff[i] + 3072u - 1024u * i;
 
   f32x16 acc[MI][NI];
 #pragma unroll
@@ -280,6 +289,9 @@ __device__ __forceinline__ void tn_unit(const TnParams& p, const int split, cons
     for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc2[mi][ni][r] = 0.f;
+  // the 16-row block: two 16 x 16 results (column halves of the wave's 32 columns)
+  f32x4 acch[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, acch2[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  const int l15 = lane & 15, lkk = lane >> 4;
   const int lane_off = (64 * wr + 4 * lh) * BT + (SK ? 32 : 64) * wc + l31;
 #define DMDX_BLOCK_OFF(mi, ni, r) ((32 * (mi) + ((r) & 3) + 8 * ((r) >> 2)) * BT + 32 * (ni))
 #define DMDX_FOLD(mi, ni)                                                         \
@@ -294,8 +306,16 @@ __device__ __forceinline__ void tn_unit(const TnParams& p, const int split, cons
         __builtin_nontemporal_store((double)(acc[mi][ni][r] + acc2[mi][ni][r]),   \
                                     q_ + DMDX_BLOCK_OFF(mi, ni, r));              \
   } while (0)
+#define DMDX_COMMIT_H16()                                                         \
+  do {                                                                            \
+    _Pragma("unroll") for (int hh = 0; hh < 2; ++hh)                              \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r)                             \
+            __builtin_nontemporal_store((double)(acch[hh][r] + acch2[hh][r]),     \
+                                        Pt + (32 * SK + 4 * lkk + r) * BT + 32 * wc + 16 * hh + l15); \
+  } while (0)
 #define DMDX_COMMIT_ALL()                                                         \
   do {                                                                            \
+    if constexpr (H16 != 0) DMDX_COMMIT_H16();                                    \
     DMDX_COMMIT(0, 0);                                                            \
     if constexpr (MI >= 2) DMDX_COMMIT(MI >= 2 ? 1 : 0, 0);                       \
     if constexpr (NI == 2) {                                                      \
@@ -324,12 +344,15 @@ __device__ __forceinline__ void tn_unit(const TnParams& p, const int split, cons
       const float* pa = Abase + k0 + aoff[i];
       ra[i] = tail ? load4_tail(pa, k0 + kqa[i], kend) : f32x4{pa[0], pa[1], pa[2], pa[3]};
     }
+    // (H16: the last piece / the last group of 32 columns is only half inside the panel)
+    const bool a_last_ok = !H16 || (DMA ? wave + 4 * (NPA - 1) < NPIECE : (tid >> 3) + 32 * (NPA - 1) < TM);
     float* as = lds + st * STG;
     float* bs = lds + st * STG + OPA;
 #pragma unroll
     for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(bs + stsb[i]) = rb[i];
 #pragma unroll
-    for (int i = 0; i < NPA; ++i) *reinterpret_cast<f32x4*>(as + stsa[i]) = ra[i];
+    for (int i = 0; i < NPA; ++i)
+      if (i + 1 < NPA || a_last_ok) *reinterpret_cast<f32x4*>(as + stsa[i]) = ra[i];
   };
 // The 8 pieces of the next chunk in one asm block: 2 SALU (M0) + 8 VMEM, no VALU.  A wave
 // whose SIMD partner streams MFMAs gets ~one instruction issued per MFMA slot (stamps:
@@ -362,7 +385,10 @@ __device__ __forceinline__ void tn_unit(const TnParams& p, const int split, cons
                : "memory")
 #define DMDX_DMA_A(ap, la)                                                                         \
   do {                                                                                             \
-    if constexpr (NPA == 4) DMDX_DMA_OP4(ap, la, aoffb[0], aoffb[1], aoffb[NPA - 2], aoffb[NPA - 1]); \
+    if constexpr (H16 != 0) {                                                                      \
+      _Pragma("unroll") for (int i_ = 0; i_ < NPA; ++i_)                                           \
+          if (i_ + 1 < NPA || wave + 4 * (NPA - 1) < NPIECE) DMDX_DMA_OP1(ap, (la) + 4096u * i_, aoffb[i_]); \
+    } else if constexpr (NPA == 4) DMDX_DMA_OP4(ap, la, aoffb[0], aoffb[1], aoffb[NPA - 2], aoffb[NPA - 1]); \
     else if constexpr (NPA == 3) DMDX_DMA_OP3(ap, la, aoffb[0], aoffb[1], aoffb[NPA - 1]);         \
     else if constexpr (NPA == 2) DMDX_DMA_OP2(ap, la, aoffb[0], aoffb[NPA - 1]);                   \
     else DMDX_DMA_OP1(ap, la, aoffb[0]);                                                           \
@@ -375,7 +401,7 @@ __device__ __forceinline__ void tn_unit(const TnParams& p, const int split, cons
   } while (0)
   auto stage_dma = [&](int chunk, int st) {
     const int64_t k0 = (int64_t)chunk * BK;
-    float* as = lds + st * STG + ((TM / 4) * wave) * BK;
+    float* as = lds + st * STG + (H16 ? 8 * wave : (TM / 4) * wave) * BK;
     float* bs = lds + st * STG + OPA + (32 * wave) * BK;
     DMDX_DMA_NEXT(Adma + 4 * k0, Bdma + 4 * k0, (unsigned)(uintptr_t)DMDX_LDS_PTR(as),
                   (unsigned)(uintptr_t)DMDX_LDS_PTR(bs));
@@ -393,12 +419,24 @@ __device__ __forceinline__ void tn_unit(const TnParams& p, const int split, cons
   // LDS while the 16 MFMAs of k-step t run.  Lane (r = lane&31, h = lane>>5) reads, for
   // k-step t, the 16-byte k-chunk (2t + h) of its column, stored at slot (2t+h) ^ swz.
   f32x4 fa0[MI], fb0[NI], fa1[MI], fb1[NI];
-  int foff[4];
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  f32x2 fa0h = {0.f, 0.f}, fa1h = {0.f, 0.f}, fb0h[2] = {{0.f, 0.f}, {0.f, 0.f}}, fb1h[2] = {{0.f, 0.f}, {0.f, 0.f}};
+  int foff[4], foffh[4];
 #pragma unroll
-  for (int t = 0; t < 4; ++t) foff[t] = l31 * BK + 4 * ((2 * t + lh) ^ swz(l31));
+  for (int t = 0; t < 4; ++t) {
+    foff[t] = l31 * BK + 4 * ((2 * t + lh) ^ swz(l31));
+    foffh[t] = l15 * BK + 4 * ((2 * t + (lkk >> 1)) ^ swz(l15)) + 2 * (lkk & 1);
+  }
   const int frag_a = 64 * wr * BK, frag_b = (SK ? 32 : 64) * wc * BK;
 #define DMDX_READ_FRAGS(FA, FB, st, t)                                               \
   do {                                                                               \
+    if constexpr (H16 != 0) {                                                        \
+      const float* ah_ = lds + (st) * STG + 32 * SK * BK + foffh[t];                 \
+      const float* bh_ = lds + (st) * STG + OPA + frag_b + foffh[t];                 \
+      FA##h = *reinterpret_cast<const f32x2*>(ah_);                                  \
+      FB##h[0] = *reinterpret_cast<const f32x2*>(bh_);                               \
+      FB##h[1] = *reinterpret_cast<const f32x2*>(bh_ + 16 * BK);                     \
+    }                                                                                \
     const float* as_ = lds + (st) * STG + frag_a + foff[t];                          \
     const float* bs_ = lds + (st) * STG + OPA + frag_b + foff[t];                    \
     FA[0] = *reinterpret_cast<const f32x4*>(as_);                                    \
@@ -436,7 +474,12 @@ __device__ __forceinline__ void tn_unit(const TnParams& p, const int split, cons
     DMDX_MFMA4(FA, FB, 1);                                         \
     DMDX_MFMA4(FA, FB, 2);                                         \
     DMDX_MFMA4(FA, FB, 3);                                         \
-    __builtin_amdgcn_sched_group_barrier(0x008, 4 * MI * NI, 0);   \
+    if constexpr (H16 != 0) {                                      \
+      _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_)             \
+          _Pragma("unroll") for (int hh_ = 0; hh_ < 2; ++hh_) acch[hh_] = \
+              __builtin_amdgcn_mfma_f32_16x16x4f32(FA##h[s_], FB##h[hh_][s_], acch[hh_], 0, 0, 0); \
+    }                                                              \
+    __builtin_amdgcn_sched_group_barrier(0x008, 4 * MI * NI + 4 * H16, 0);   \
   } while (0)
 
 #ifdef DMDX_STAMPS
@@ -451,13 +494,13 @@ __device__ __forceinline__ void tn_unit(const TnParams& p, const int split, cons
     const int phase = c & (FOLD / 4 - 1), fq = (c / (FOLD / 4)) & 3;
     DMDX_STAMP(st1);
     DMDX_READ_FRAGS(fa1, fb1, cur, 1);
-    __builtin_amdgcn_sched_group_barrier(0x100, MI + NI, 0);   // ds_reads of the next fragments
+    __builtin_amdgcn_sched_group_barrier(0x100, MI + NI + 3 * H16, 0);   // ds_reads of the next fragments
     DMDX_KSTEP(fa0, fb0, 0);
     DMDX_READ_FRAGS(fa0, fb0, cur, 2);
-    __builtin_amdgcn_sched_group_barrier(0x100, MI + NI, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, MI + NI + 3 * H16, 0);
     DMDX_KSTEP(fa1, fb1, 1);
     DMDX_READ_FRAGS(fa1, fb1, cur, 3);
-    __builtin_amdgcn_sched_group_barrier(0x100, MI + NI, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, MI + NI + 3 * H16, 0);
     DMDX_KSTEP(fa0, fb0, 2);
     DMDX_STAMP(st2);
 
@@ -468,7 +511,7 @@ __device__ __forceinline__ void tn_unit(const TnParams& p, const int split, cons
     cur ^= 1;
     DMDX_STAMP(st3);
     if (has_next) DMDX_READ_FRAGS(fa0, fb0, cur, 0);
-    __builtin_amdgcn_sched_group_barrier(0x100, MI + NI, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, MI + NI + 3 * H16, 0);
     DMDX_KSTEP(fa1, fb1, 3);
     if (!(ABL & 8) && phase == FOLD / 4 - 1) {
       switch (fq) {
@@ -478,7 +521,16 @@ __device__ __forceinline__ void tn_unit(const TnParams& p, const int split, cons
           else if constexpr (MI == 3) { DMDX_FOLD(MI - 1, 0); }
           break;
         case 2: if constexpr (MI >= 2) { DMDX_FOLD(MI >= 2 ? 1 : 0, 0); } break;
-        default: if constexpr (NI == 2) { DMDX_FOLD(1, NI - 1); } break;
+        default:
+          if constexpr (NI == 2) { DMDX_FOLD(1, NI - 1); }
+          if constexpr (H16 != 0) {
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+              acch2[hh] += acch[hh];
+              acch[hh] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+          }
+          break;
       }
     }
 #ifdef DMDX_STAMPS
@@ -510,6 +562,7 @@ __device__ __forceinline__ void tn_unit(const TnParams& p, const int split, cons
 #undef DMDX_DMA_OP3
 #undef DMDX_FOLD
 #undef DMDX_COMMIT_ALL
+#undef DMDX_COMMIT_H16
 #undef DMDX_COMMIT
 #undef DMDX_BLOCK_OFF
 }
@@ -522,9 +575,9 @@ __device__ __forceinline__ int xcd_unit(int b, int total) {
   return ((g << 9) + 512 <= total) ? (g << 9) + (b & 7) * 64 + ((b & 511) >> 3) : b;
 }
 
-template <bool DMA, int ABL = 0, int SK = 0>
+template <bool DMA, int ABL = 0, int SK = 0, int H16 = 0>
 __global__ __launch_bounds__(NTH, 2) void gemm_tn_partial_kernel(TnParams p) {
-  constexpr int TM = SK ? 32 * SK : BT;
+  constexpr int TM = SK ? 32 * SK + 16 * H16 : BT;
   __shared__ __attribute__((aligned(16))) float lds[2 * (TM + BT) * BK];
   const int pos = xcd_unit(blockIdx.x, gridDim.x);
   const int split = pos / p.ntiles;
@@ -532,14 +585,14 @@ __global__ __launch_bounds__(NTH, 2) void gemm_tn_partial_kernel(TnParams p) {
   int ta, tb;
   decode_tile(p, tile, ta, tb);
   double* Pt = p.P + ((size_t)split * p.ntiles + tile) * (TM * BT);
-  tn_unit<DMA, ABL, SK>(p, split, ta * TM, tb * BT, Pt, lds);
+  tn_unit<DMA, ABL, SK, H16>(p, split, ta * TM, tb * BT, Pt, lds);
 }
 
 // D (+)= sum_j A_j^T B_j over a batch of row blocks (TnBatch); p carries what the blocks share
 // (shape of D, tiles, P).  SYRK: A_j == B_j, triangle tiles.
-template <bool DMA, int SK = 0>
+template <bool DMA, int SK = 0, int H16 = 0>
 __global__ __launch_bounds__(NTH, 2) void syrk_batch_kernel(TnParams p, TnBatch bt) {
-  constexpr int TM = SK ? 32 * SK : BT;
+  constexpr int TM = SK ? 32 * SK + 16 * H16 : BT;
   __shared__ __attribute__((aligned(16))) float lds[2 * (TM + BT) * BK];
   const int b = blockIdx.x;
   int j = 0;
@@ -567,7 +620,7 @@ __global__ __launch_bounds__(NTH, 2) void syrk_batch_kernel(TnParams p, TnBatch 
     c0 = __builtin_amdgcn_s_memtime();
     r0 = __builtin_amdgcn_s_memrealtime();
   }
-  tn_unit<DMA, 0, SK>(p, split, ta * TM, tb * BT, Pt, lds);
+  tn_unit<DMA, 0, SK, H16>(p, split, ta * TM, tb * BT, Pt, lds);
   if (bt.clk != nullptr) {
     const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
     if (threadIdx.x == 0) {
@@ -585,8 +638,8 @@ __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(
     const double* P, int nsplit, int ntiles, int ntr, int ntc, int syrk, int nrow, int ncol,
     double* D64, int64_t ld64, float* D32, int64_t ld32, int accumulate, int tm) {
   __shared__ double tr[32][33];
-  // one workgroup per (tile, 32x32 sub-block); a tile is tm (64, 96 or 128) rows x 128 columns
-  const int nsb = (tm / 32) * 4;
+  // one workgroup per (tile, 32x32 sub-block); a tile is tm (32 ... 128, a multiple of 16) rows x 128 columns
+  const int nsb = ((tm + 31) / 32) * 4;
   const int tile = blockIdx.x / nsb;
   const int sb = blockIdx.x - tile * nsb;
   const int tile_elems = tm * BT;
@@ -613,13 +666,14 @@ __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(
   for (int sp = 0; sp < nsplit; ++sp) {
     const double* q = src + (size_t)sp * ntiles * tile_elems;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) v[k] += q[8 * k * BT];
+    for (int k = 0; k < 4; ++k)
+      if (si + ty + 8 * k < tm) v[k] += q[8 * k * BT];   // (a 48- / 80- / 112-row tile ends inside its last sub-block row)
   }
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int i = si + ty + 8 * k, j = sj + tx;
     const int gi = row0 + i, gj = col0 + j;
-    const bool keep = !(diag && i > j);
+    const bool keep = !(diag && i > j) && i < tm;
     if (keep && gi < nrow && gj < ncol) {
       double o = v[k];
       if (accumulate) o += D64[(int64_t)gi * ld64 + gj];
@@ -636,7 +690,7 @@ __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(
       const int i = si + tx, j = sj + ty + 8 * k;
       const double s = tr[tx][ty + 8 * k];
       const int gi = row0 + i, gj = col0 + j;
-      const bool keep = !(diag && i >= j);
+      const bool keep = !(diag && i >= j) && i < tm;
       if (keep && gi < nrow && gj < ncol) {
         double o = s;
         if (accumulate) o += D64[(int64_t)gj * ld64 + gi];
@@ -665,10 +719,17 @@ Plan make_plan(int64_t K, int64_t nrow, int64_t ncol, int syrk, int share = 1) {
   pl.syrk = syrk;
   if (!syrk) {  // fewest padded rows; ties go to the taller tile (fewer re-reads of the B panels)
     int64_t best = (nrow + BT - 1) / BT * BT;
-    for (int tm : {96, 64, 32}) {
+    for (int tm : {112, 96, 80, 64, 48, 32}) {
+      // (a Gram keeps to the 32-row blocks: the 16-row block contracts k in another order, and
+      // G[i][j] would differ from G[j][i] in the last bits)
+      if (gram && tm % 32) continue;
       const int64_t padded = (nrow + tm - 1) / tm * tm;
-      if (padded < best && (tm > 32 || nrow <= 32)) { best = padded; pl.tm = tm; }   // 32-row tiles: single tile row only
+      if (padded < best && (tm > 48 || nrow <= tm)) { best = padded; pl.tm = tm; }   // 32- / 48-row tiles: single tile row only
     }
+  }
+  if (const char* e = getenv("DMDX_TN_FORCE_TM")) {   // A/B knob (scripts/ab_k3.py): a tile height for the plain products
+    const int f = atoi(e);
+    if (!syrk && f >= 32 && f <= 128 && f % 16 == 0 && (f > 48 || nrow <= f)) pl.tm = f;
   }
   pl.ntr = (int)((nrow + pl.tm - 1) / pl.tm);
   pl.ntc = (int)((ncol + BT - 1) / BT);
@@ -740,24 +801,24 @@ int run_tn(const float* A, int64_t lda, const float* B, int64_t ldb, int64_t K, 
     hipLaunchKernelGGL((gemm_tn_partial_kernel<true, 8>), grid, dim3(NTH), 0, stream, p);
   else if (aligned && abl == 11)
     hipLaunchKernelGGL((gemm_tn_partial_kernel<true, 11>), grid, dim3(NTH), 0, stream, p);
-  else if (aligned && pl.tm == 64)  // LDS-DMA staging needs 16-byte aligned column starts
-    hipLaunchKernelGGL((gemm_tn_partial_kernel<true, 0, 2>), grid, dim3(NTH), 0, stream, p);
-  else if (aligned && pl.tm == 96)
-    hipLaunchKernelGGL((gemm_tn_partial_kernel<true, 0, 3>), grid, dim3(NTH), 0, stream, p);
-  else if (aligned && pl.tm == 32)
-    hipLaunchKernelGGL((gemm_tn_partial_kernel<true, 0, 1>), grid, dim3(NTH), 0, stream, p);
-  else if (aligned)
+  else if (pl.tm != BT) {  // skinny tiles (LDS-DMA staging needs 16-byte aligned column starts)
+#define DMDX_TN_CASE(TMV, SKV, HV)                                                                          \
+    case TMV:                                                                                               \
+      if (aligned) hipLaunchKernelGGL((gemm_tn_partial_kernel<true, 0, SKV, HV>), grid, dim3(NTH), 0, stream, p);  \
+      else hipLaunchKernelGGL((gemm_tn_partial_kernel<false, 0, SKV, HV>), grid, dim3(NTH), 0, stream, p);  \
+      break
+    switch (pl.tm) {
+      DMDX_TN_CASE(32, 1, 0); DMDX_TN_CASE(48, 1, 1); DMDX_TN_CASE(64, 2, 0); DMDX_TN_CASE(80, 2, 1);
+      DMDX_TN_CASE(96, 3, 0); DMDX_TN_CASE(112, 3, 1);
+      default: dmdx_set_error("gemm_tn: no kernel for tile height %d", pl.tm); return DMDX_E_INVALID;
+    }
+#undef DMDX_TN_CASE
+  } else if (aligned)
     hipLaunchKernelGGL(gemm_tn_partial_kernel<true>, grid, dim3(NTH), 0, stream, p);
-  else if (pl.tm == 64)
-    hipLaunchKernelGGL((gemm_tn_partial_kernel<false, 0, 2>), grid, dim3(NTH), 0, stream, p);
-  else if (pl.tm == 96)
-    hipLaunchKernelGGL((gemm_tn_partial_kernel<false, 0, 3>), grid, dim3(NTH), 0, stream, p);
-  else if (pl.tm == 32)
-    hipLaunchKernelGGL((gemm_tn_partial_kernel<false, 0, 1>), grid, dim3(NTH), 0, stream, p);
   else
     hipLaunchKernelGGL(gemm_tn_partial_kernel<false>, grid, dim3(NTH), 0, stream, p);
   DMDX_LAUNCH_CHECK();
-  hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3(pl.ntiles * (pl.tm / 32) * 4), dim3(256), 0, stream, p.P,
+  hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3(pl.ntiles * ((pl.tm + 31) / 32) * 4), dim3(256), 0, stream, p.P,
                      pl.nsplit, pl.ntiles, pl.ntr, pl.ntc, pl.syrk, (int)nrow, (int)ncol, D64, ld64, D32, ld32,
                      accumulate, pl.tm);
   DMDX_LAUNCH_CHECK();
@@ -823,21 +884,19 @@ int run_batch(const float* const* A, const int64_t* lda, const float* const* B, 
     p.nsplit = slabs;
     p.P = reinterpret_cast<double*>(ws);
     const dim3 grid((unsigned)units);
-    if (pl.tm == 64) {
-      if (aligned) hipLaunchKernelGGL((syrk_batch_kernel<true, 2>), grid, dim3(NTH), 0, stream, p, bt);
-      else hipLaunchKernelGGL((syrk_batch_kernel<false, 2>), grid, dim3(NTH), 0, stream, p, bt);
-    } else if (pl.tm == 96) {
-      if (aligned) hipLaunchKernelGGL((syrk_batch_kernel<true, 3>), grid, dim3(NTH), 0, stream, p, bt);
-      else hipLaunchKernelGGL((syrk_batch_kernel<false, 3>), grid, dim3(NTH), 0, stream, p, bt);
-    } else if (pl.tm == 32) {
-      if (aligned) hipLaunchKernelGGL((syrk_batch_kernel<true, 1>), grid, dim3(NTH), 0, stream, p, bt);
-      else hipLaunchKernelGGL((syrk_batch_kernel<false, 1>), grid, dim3(NTH), 0, stream, p, bt);
-    } else {
-      if (aligned) hipLaunchKernelGGL((syrk_batch_kernel<true, 0>), grid, dim3(NTH), 0, stream, p, bt);
-      else hipLaunchKernelGGL((syrk_batch_kernel<false, 0>), grid, dim3(NTH), 0, stream, p, bt);
+    switch (pl.tm) {
+#define DMDX_TN_CASE(TMV, SKV, HV)                                                                          \
+      case TMV:                                                                                             \
+        if (aligned) hipLaunchKernelGGL((syrk_batch_kernel<true, SKV, HV>), grid, dim3(NTH), 0, stream, p, bt);    \
+        else hipLaunchKernelGGL((syrk_batch_kernel<false, SKV, HV>), grid, dim3(NTH), 0, stream, p, bt);    \
+        break
+      DMDX_TN_CASE(32, 1, 0); DMDX_TN_CASE(48, 1, 1); DMDX_TN_CASE(64, 2, 0); DMDX_TN_CASE(80, 2, 1);
+      DMDX_TN_CASE(96, 3, 0); DMDX_TN_CASE(112, 3, 1); DMDX_TN_CASE(128, 0, 0);
+#undef DMDX_TN_CASE
+      default: dmdx_set_error("gemm_tn_blocks: no kernel for tile height %d", pl.tm); return DMDX_E_INVALID;
     }
     DMDX_LAUNCH_CHECK();
-    hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3(pl.ntiles * (pl.tm / 32) * 4), dim3(256), 0, stream, p.P, slabs,
+    hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3(pl.ntiles * ((pl.tm + 31) / 32) * 4), dim3(256), 0, stream, p.P, slabs,
                        pl.ntiles, pl.ntr, pl.ntc, pl.syrk, (int)nrow, (int)ncol, D64, ld64, D32, ld32,
                        (accumulate || j0 > 0) ? 1 : 0, pl.tm);
     DMDX_LAUNCH_CHECK();
@@ -1163,10 +1222,10 @@ int dmdx_syrk_blocks_f32(const float* const* X, const int64_t* m, const int64_t*
 static int64_t tn_row_split(int64_t nrow) {
   if (nrow <= BT) return 0;
   const int64_t full = nrow / BT * BT, rem = nrow - full;
-  if (rem == 0 || rem > 96) return 0;
-  const int64_t rem_pad = rem <= 64 ? 64 : 96;
+  if (rem == 0 || rem > 112) return 0;
+  const int64_t rem_pad = rem <= 32 ? 32 : (rem + 15) / 16 * 16;
   int64_t best = (nrow + BT - 1) / BT * BT;
-  for (int tm : {96, 64}) {
+  for (int tm : {112, 96, 80, 64}) {
     const int64_t padded = (nrow + tm - 1) / tm * tm;
     if (padded < best) best = padded;
   }

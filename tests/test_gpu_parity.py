@@ -89,7 +89,11 @@ def test_syrk_large_properties(K):
 # ---------------------------------------------------------------- K3 GEMM_TN
 @pytest.mark.parametrize("K_,na,nb", [(64, 3, 2), (5000, 200, 190), (4099, 130, 131), (1000, 130, 60), (4097, 300, 70), (50000, 192, 220),
                                        (3001, 257, 33), (20000, 140, 150), (777, 64, 64), (5000, 1000, 129),
-                                       (200000, 300, 90), (99999, 128, 96), (65536, 3653, 70)])   # 96-row tiles
+                                       (200000, 300, 90), (99999, 128, 96), (65536, 3653, 70),   # 96-row tiles (round 2); 70 -> one 80-row tile (round 3)
+                                       # round 3, tile heights with a 16-row block on the 16x16x4 MFMA: 48 / 80 / 112 rows, alone, stacked,
+                                       # below full 128-row tiles (200 = 128 + 80, 220 = 128 + 96), unaligned ld (K odd), K % 32 != 0
+                                       (5000, 200, 40), (4099, 130, 48), (30000, 257, 72), (30001, 257, 80), (3000, 150, 100),
+                                       (3002, 150, 112), (30000, 192, 200), (8191, 129, 160), (100, 128, 70)])
 def test_gemm_tn(K, K_, na, nb):
     rs = np.random.RandomState(K_ + na + nb)
     A = _rand(rs, K_, na)
@@ -790,7 +794,8 @@ def test_syrk_blocks_equals_sum_of_block_grams(K, sizes, n):
 
 
 @pytest.mark.parametrize("sizes,na,nb", [([5000, 3000, 4097], 60, 260), ([700] * 19, 70, 200), ([30001, 29999], 130, 129),
-                                         ([40000] * 5 + [39996], 200, 80), ([8191, 4093], 129, 65)])
+                                         ([40000] * 5 + [39996], 200, 80), ([8191, 4093], 129, 65),
+                                         ([4096] * 3, 300, 72), ([5000, 3001], 129, 104), ([130872] * 3, 3653, 70), ([999] * 18, 140, 210)])
 def test_gemm_tn_blocks_equals_sum_of_block_products(K, sizes, na, nb):
     """dmdx_gemm_tn_blocks_f32 against the fp64 product of the stacked rows: ragged block sizes,
     > 16 blocks, 64-, 96- and 128-row tiles, accumulation into an existing C."""

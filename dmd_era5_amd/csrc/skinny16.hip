@@ -170,6 +170,14 @@ __global__ __launch_bounds__(256, WPS) void skinny16_kernel(
     __builtin_amdgcn_sched_group_barrier(0x100, hi_ - lo_, 0);                                 \
   } while (0)
   // the MFMAs of step k: 4 k-steps x 4 row blocks x its column blocks, on the 4 X quads of its half
+#if defined(DMDX_K2_ABL) && (DMDX_K2_ABL & 1)   /* timing only: no MFMAs */
+#define DMDX_MFMA_STEP(k)                                                                      \
+  do {                                                                                         \
+    constexpr int g_ = (k) / NPART;                                                            \
+    _Pragma("unroll") for (int s = 0; s < 4; ++s) asm volatile("" ::"v"(xq[g_][s]));           \
+    _Pragma("unroll") for (int c = 0; c < PB; ++c) asm volatile("" ::"v"(bb[(k) & 1][c]));     \
+  } while (0)
+#else
 #define DMDX_MFMA_STEP(k)                                                                      \
   do {                                                                                         \
     constexpr int g_ = (k) / NPART, lo_ = PB * ((k) % NPART);                                  \
@@ -180,6 +188,7 @@ __global__ __launch_bounds__(256, WPS) void skinny16_kernel(
                 __builtin_amdgcn_mfma_f32_16x16x4f32(xq[g_][s][e], bb[(k) & 1][c - lo_][s], acc[e][c], 0, 0, 0); \
     __builtin_amdgcn_sched_group_barrier(0x008, 16 * (hi_ - lo_), 0);                          \
   } while (0)
+#endif
 
   const int nchunks = (int)((n + KB - 1) / KB);
   f32x4 xq[2][4];   // X quads of the current chunk: [half g][s] = lane column k0 + 16 g + s + 4 kk
@@ -219,8 +228,14 @@ __global__ __launch_bounds__(256, WPS) void skinny16_kernel(
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         if constexpr (FAST) {
+#if defined(DMDX_K2_ABL) && (DMDX_K2_ABL & 2)   /* timing only: no X loads */
+          f32x4 v = {(float)s, 1.f, 2.f, 3.f};
+          asm volatile("" : "+v"(v));
+          xq[g][s] = v;
+#else
           xq[g][s] = __builtin_bit_cast(
               f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)loffb, (16 * g + s) * (int)ldxb, 0));
+#endif
         } else {
           xq[g][s] = load_x(k0 + KB + 16 * g + s);
         }
@@ -228,9 +243,13 @@ __global__ __launch_bounds__(256, WPS) void skinny16_kernel(
       if constexpr (FAST) __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);
     };
     auto publish = [&]() {   // W chunk c + 1 into the other stage; every wave is done reading this one
+#if defined(DMDX_K2_ABL) && (DMDX_K2_ABL & 4)   /* timing only: no W staging, no barrier */
+      cur ^= 1;
+#else
       if (has_next) store_w(cur ^ 1);
       __syncthreads();
       cur ^= 1;
+#endif
     };
     if (has_next) {
       if constexpr (FAST) load_w_fast(k0 + KB);

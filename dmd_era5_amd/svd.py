@@ -594,7 +594,7 @@ def _gemm_tn_blocks(Ablocks, Bblocks, kern, comm: Comm) -> torch.Tensor:
     return comm.allreduce_sum_(C)
 
 
-def _project_blocks(kern, Xblocks, Wt: torch.Tensor, d: int):
+def _project_blocks(kern, Xblocks, Wt: torch.Tensor, d: int, whole: torch.Tensor | None = None):
     """[X_b W for every row block] -> (blocks, whole).  Without delay embedding the per-block
     results are written straight into column slices of ONE (l, M) tensor (``whole``; the blocks
     are views of it), so that assembling U is not a second copy of it -- at cfg4 that copy was a
@@ -604,7 +604,8 @@ def _project_blocks(kern, Xblocks, Wt: torch.Tensor, d: int):
     if d != 1 or len(Xblocks) == 1:
         return [kern.skinny(X, Wt) for X in Xblocks], None
     M = sum(int(X.shape[1]) for X in Xblocks)
-    whole = torch.empty((Wt.shape[0], M), dtype=torch.float32, device=Xblocks[0].device)
+    if whole is None or tuple(whole.shape) != (Wt.shape[0], M):
+        whole = torch.empty((Wt.shape[0], M), dtype=torch.float32, device=Xblocks[0].device)
     views, off = [], 0
     for X in Xblocks:
         mb = int(X.shape[1])
@@ -649,6 +650,26 @@ def _sign_flip(Ublocks, Vh: torch.Tensor, comm: Comm, kern):
         kern.scale_columns_(Ut, sign.to(torch.float32))
     Vh = Vh * sign.to(Vh.dtype)[:, None]
     return Ublocks, Vh
+
+
+class _PhaseClock:
+    """Wall time per phase of a driver, for reporting only (``timings=True``: every call
+    synchronises the device, so the phases no longer overlap with the host)."""
+
+    def __init__(self, device, on: bool):
+        self.dev, self.on, self.acc = device, bool(on), {}
+        self.t = self._now() if self.on else 0.0
+
+    def _now(self) -> float:
+        if self.dev.type == "cuda":
+            torch.cuda.synchronize(self.dev)
+        return time.perf_counter()
+
+    def __call__(self, name: str) -> None:
+        if self.on:
+            t = self._now()
+            self.acc[name] = self.acc.get(name, 0.0) + (t - self.t)
+            self.t = t
 
 
 def _sync_time(device) -> float:
@@ -1206,6 +1227,42 @@ def _cholqr(Yb, comm: Comm, kern, passes: int = 1, G0: torch.Tensor | None = Non
     return Yb
 
 
+def _chol_rinv(G: torch.Tensor, comm: Comm):
+    """R^-1 (upper triangular, fp64) of the Cholesky factorisation G = R^T R of the Gram matrix of a
+    tall block Y, plus how far it can be trusted: -> (Rinv, shifted, spread) with ``spread`` =
+    min / max of R's diagonal (~ 1 / cond(Y)).  The Gram of fp32 products of an oversampled
+    range-finder block can be numerically indefinite; then G + s I is factored instead with the
+    smallest s of an escalating list that works (shifted CholeskyQR, Fukaya et al. 2020: Y R^-1 is
+    then not orthonormal but has a condition number <= ~1e3) and ``shifted`` is True.  None if Y is
+    exactly zero (X = 0).  Rank 0's factor is made authoritative (one small broadcast)."""
+    l = G.shape[0]
+    eye = torch.eye(l, dtype=torch.float64, device=G.device)
+    G = 0.5 * (G + G.T)
+    L, err = torch.linalg.cholesky_ex(G)
+    diag = torch.diagonal(L)
+    # (one read-back for the three checks: every host round trip is a bubble in the launch stream)
+    st = torch.stack([(err != 0).double().reshape(()), (~torch.isfinite(diag).all()).double(),
+                      diag.min() / diag.max().clamp_min(1e-300)]).tolist()
+    bad = st[0] != 0.0 or st[1] != 0.0 or not (st[2] >= 1e-4)
+    shifted = False
+    if bad:
+        tr = torch.diagonal(G).sum()
+        if float(tr) == 0.0 and bool(torch.isfinite(G).all()):
+            return None
+        for rel in (1e-6, 3e-5, 1e-3, 3e-2):
+            L, err = torch.linalg.cholesky_ex(G + (rel * tr) * eye)
+            if int(err) == 0 and bool(torch.isfinite(torch.diagonal(L)).all()):
+                break
+        else:
+            raise np.linalg.LinAlgError("CholeskyQR: the Gram matrix of the range-finder block is not finite")
+        shifted = True
+        diag = torch.diagonal(L)
+        st[2] = float(diag.min() / diag.max().clamp_min(1e-300))
+    Rinv = torch.linalg.solve_triangular(L.T, eye, upper=True).contiguous()   # R = L^T
+    comm.broadcast_(Rinv)
+    return Rinv, shifted, float(st[2])
+
+
 def resolve_n_iter(n_components: int, m: int, n: int, n_iter="auto") -> int:
     """extmath.py:557-560."""
     if n_iter == "auto":
@@ -1264,29 +1321,86 @@ def svd_randomized(Xt, n_components: int, delay: int = 1, n_oversamples: int = 1
     if tuple(Qt.shape) != (l, nd):
         raise ValueError(f"omega must be ({nd}, {l}), got {tuple(Qt.shape)[::-1]}")
     t0 = _sync_time(dev) if timings else 0.0
+    # The (k, M) result is allocated FIRST: requested at the end, next to X and the m x l iterates
+    # (cfg4: 227.6 + 13.7 GB resident, 12.5 GB wanted), the caching allocator finds its one cached
+    # block of that size cut up by the 119 Y blocks of the iterations, hands cached segments back to
+    # the driver and asks again -- 350 ms with the GPU idle at the end of every SVD.
+    U_out = None
+    if delay == 1 and len(Eb) > 1:
+        U_out = torch.empty((k, sum(int(E.shape[1]) for E in Eb)), dtype=torch.float32, device=dev)
 
+    # Normalisation of the iterates WITHOUT a pass over the m x l matrix (round 3).  sklearn
+    # normalises Y = X Q before the next product (extmath.py:349-351); with CholeskyQR that is
+    # Y R^-1, G = Y^T Y = R^T R.  But X^T (Y R^-1) = (X^T Y) R^-1: the triangular factor is applied to
+    # the small n x l result instead (fp64), Y itself is only ever read by K3 -- the same subspace,
+    # one fp32 rounding of Y less, and at cfg4 (l = 220) four passes over a 13.7 GB matrix less
+    # per SVD.  G comes out of the K2 launches that produce Y (fused Gram, l <= 224).
+    phase = _PhaseClock(dev, timings)
     for _ in range(n_it):
         Qp = _pitched(kern, Qt)
         if normalise:
             Yb, G0 = _project_with_gram(kern, Eb, Qp, comm)   # Y = X Q (extmath.py:350) + its Gram
-            Yb = _cholqr(Yb, comm, kern, G0=G0)
+            if G0 is None:
+                G0 = _gram_blocks(Yb, kern, comm)
+            phase("k2")
+            fac = _chol_rinv(G0, comm)
+            phase("small")
         else:
-            Yb = [kern.skinny(E, Qp) for E in Eb]
+            Yb, fac = [kern.skinny(E, Qp) for E in Eb], None
+            phase("k2")
         Zt = _gemm_tn_blocks(Eb, Yb, kern, comm)  # Z = X^T Y, (l, nd) (extmath.py:351)
+        del Yb
+        phase("k3")
         if normalise:
+            if fac is not None:
+                Zt = fac[0].T @ Zt                # Z R^-1, in the (l, nd) layout
             Qt = _orth(Zt.T.contiguous(), kern=kern).T.contiguous().to(torch.float32)
         else:
             Qt = Zt.to(torch.float32)
         comm.broadcast_(Qt)
+        phase("small")
+    # Final basis (extmath.py:355, `Q, _ = qr(A @ Q)`): CholeskyQR2 with its LAST triangular factor
+    # deferred the same way.  Y_1 = Y R_0^-1 is formed explicitly (one K2 pass over Y, its Gram fused
+    # in); if Y_1 is well conditioned (it is nearly orthonormal unless R_0 came from a shifted
+    # factorisation, in which case one more explicit pass follows) the second factor R_1 is never
+    # applied to the tall matrix: B = Q^T X = R_1^-T (Y_1^T X) and U = Q Uhat = Y_1 (R_1^-1 Uhat).
     Qp = _pitched(kern, Qt)
-    Yb, G0 = _project_with_gram(kern, Eb, Qp, comm)        # extmath.py:355
-    Qmb = _cholqr(Yb, comm, kern, passes=2, G0=G0)         # orthonormal basis of range(Y)
-    Bm = _gemm_tn_blocks(Eb, Qmb, kern, comm)    # (l, nd) = Q^T X    (extmath.py:577)
+    Yb, G = _project_with_gram(kern, Eb, Qp, comm)        # Y_0 = X Q
+    if G is None:
+        G = _gram_blocks(Yb, kern, comm)
+    phase("k2")
+    fused = int(G.shape[0]) <= getattr(kern, "skinny_gram_max_l", 0)
+    Rlast = None
+    for explicit in range(4):
+        fac = _chol_rinv(G, comm)
+        if fac is None:                                    # Y is exactly zero (X = 0): s comes out 0
+            break
+        Rinv, shifted, spread = fac
+        if explicit >= 1 and not shifted and spread > 0.5:
+            Rlast = Rinv                                   # well conditioned: deferred
+            break
+        Rt = _pitched(kern, Rinv.T.contiguous().to(torch.float32))
+        G = torch.zeros_like(G) if fused else None
+        for i in range(len(Yb)):                           # Y_{j+1} = Y_j R_j^-1, block by block, Gram fused in
+            Yb[i] = kern.skinny(Yb[i], Rt, gram=G) if fused else kern.skinny(Yb[i], Rt)
+        G = comm.allreduce_sum_(G) if fused else _gram_blocks(Yb, kern, comm)
+    info["cholqr_explicit_passes"] = explicit
+    phase("cholqr")
+    Qmb = Yb
+    Bm = _gemm_tn_blocks(Eb, Qmb, kern, comm)    # (l, nd) = Y_1^T X
+    phase("k3")
+    if Rlast is not None:
+        Bm = Rlast.T @ Bm                        # = Q^T X    (extmath.py:577)
     Uhat, s, Vh = _svd_wide(Bm, kern)
     Uhat, s, Vh = Uhat.contiguous(), s.contiguous(), Vh.contiguous()
     comm.broadcast_(Uhat, s, Vh)
-    Uk = _pitched(kern, Uhat[:, :k].T.contiguous().to(torch.float32))
-    Ub, whole = _project_blocks(kern, Qmb, Uk, delay)   # U = Q Uhat
+    Uk = Uhat[:, :k] if Rlast is None else Rlast @ Uhat[:, :k]
+    Uk = _pitched(kern, Uk.T.contiguous().to(torch.float32))
+    phase("small")
+    Ub, whole = _project_blocks(kern, Qmb, Uk, delay, whole=U_out)   # U = Q Uhat = Y_1 (R_1^-1 Uhat)
+    phase("project")
+    if timings:
+        info["phase_ms"] = {k_: v_ * 1e3 for k_, v_ in phase.acc.items()}
     s = s[:k]
     Vh = Vh[:k].contiguous()
     if flip_sign:

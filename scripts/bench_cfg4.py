@@ -35,3 +35,7 @@ flops = 6 * 2.0 * a.m * a.n * (a.k + 20)
 print(f"cfg4 k={a.k}: {dt*1e3:.0f} ms -> {a.m*a.n*4/dt/1e9:.1f} GB/s of X, {flops/dt/1e12:.1f} TFLOP/s algorithmic "
       f"(6 passes x 2mnl); with per-launch events {dt_ev*1e3:.0f} ms, kernel ms {ev}; peak HBM {torch.cuda.max_memory_allocated()/1e9:.1f} GB", flush=True)
 print("s head", res.s[:4].tolist())
+torch.cuda.synchronize(); t0 = time.perf_counter()
+rp = dsvd.svd_randomized(blocks, a.k, n_oversamples=20, n_iter=2, random_state=0, kern=kern, timings=True)
+print("phases (synchronised run, %.0f ms):" % ((time.perf_counter() - t0) * 1e3), {k: round(v) for k, v in rp.info["phase_ms"].items()},
+      "explicit CholeskyQR passes", rp.info.get("cholqr_explicit_passes"), flush=True)

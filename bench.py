@@ -410,13 +410,26 @@ def main():
     # thousands of launches per step, where recording them would be the thing measured
     kern.events = [] if svd_type == "standard" else None
     issued = comm.n_collectives
+    if hasattr(comm, "start_timing"):
+        comm.start_timing()          # one HIP event pair per collective (6 per standard step)
+    # per step: a HIP event at its start / end on the launch stream (no host synchronisation) and
+    # the clock-probe counters of its stamped kernels (K1 / K2 / K3: three atomics per workgroup)
+    step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    clk = torch.zeros((max(args.steps, 1), 3), dtype=torch.int64, device=device)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        step_ev[i].record()
+        kern.clock_probe(clk[i])
         res = step()
+    step_ev[args.steps].record()
+    kern.clock_probe(None)
     barrier()
     dt = time.perf_counter() - t0
     issued = (comm.n_collectives - issued) / max(args.steps, 1)
+    coll = comm.stop_timing() if hasattr(comm, "stop_timing") else {}
     events, kern.events = (kern.events or []), None
+    step_ms = [step_ev[i].elapsed_time(step_ev[i + 1]) for i in range(args.steps)]
+    step_clock = [100.0 * c / t if t > 0 else None for c, t, _ in clk.tolist()]
     if dist is not None:
         tmax = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -455,7 +468,13 @@ def main():
         "world_size": world,
         "backend": backend,
         "collectives_per_step": issued,     # what this rank handed to torch.distributed inside the timed region
+        # wall time of this rank's collectives inside the timed region, per step, by kind (HIP events
+        # around each call on the launch stream; gloo: host clock): so that a multi-GPU line explains itself
+        "collective_ms": {k: {"calls_per_step": v["calls"] / max(args.steps, 1), "ms_per_step": v["ms"] / max(args.steps, 1),
+                              "bytes_per_step": v["bytes"] / max(args.steps, 1)} for k, v in coll.items()},
         "devices": devices,
+        "step_ms": step_ms,                 # every timed step (HIP events on the launch stream, rank 0)
+        "step_core_clock_mhz": step_clock,  # core clock held by the stamped kernels (K1 / K2 / K3) of each step
     }
     if svd_type == "standard":
         syrk_ms = float(np.mean(by_name["syrk"]))            # average Gram launch (all row blocks of X)
@@ -467,7 +486,7 @@ def main():
         # note of MI355X_MICROARCH.md, plus WRITE_SIZE, per launch).
         traffic, traffic_src = None, None
         if args.workload == "cfg2" and args.spectrum == "planted":
-            for name in ("r2_bench_rocprof_summary.json", "r1_bench_rocprof_summary.json"):
+            for name in ("r3_bench_rocprof_summary.json", "r2_bench_rocprof_summary.json", "r1_bench_rocprof_summary.json"):
                 try:
                     with open(os.path.join(ROOT, "profiles", name)) as f:
                         traffic = float(json.load(f)["traffic"]["bytes_per_launch_corrected"])
@@ -475,6 +494,10 @@ def main():
                     break
                 except Exception:
                     continue
+        per_launch = [float(x) for x in by_name["syrk"]]      # one Gram launch per timed step, in order
+        fr = [flops / (x * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS for x in per_launch]
+        nf = min(5, len(fr))
+        clocks = [c for c in step_clock if c]
         out["roofline"] = {
             "bound": "mfma",
             "kernel": "syrk_batch_kernel (K1 Gram of all row blocks in one launch, dmdx_syrk_blocks_f32)",
@@ -486,24 +509,39 @@ def main():
             "traffic_unit": f"bytes/launch (L2<->fabric, PMC; profiles/{traffic_src})" if traffic_src else None,
             "flops_per_launch": flops,
             "ms_per_launch": syrk_ms,
+            # what the kernel SUSTAINS: `frac` is the mean over the timed steps; the chip warms up over
+            # the first ~20 steps (it gives clock back), so a long run ends lower than it starts
+            "frac_first5": float(np.mean(fr[:nf])), "frac_last5": float(np.mean(fr[-nf:])),
+            "frac_min": float(min(fr)), "frac_max": float(max(fr)),
+            "core_clock_mhz_first5": float(np.mean(clocks[:nf])) if clocks else None,
+            "core_clock_mhz_last5": float(np.mean(clocks[-nf:])) if clocks else None,
+            # the same launches priced at the clock the chip actually held (nominal: 2400 MHz)
+            "frac_at_held_clock": float(np.mean([f * 2400.0 / c for f, c in zip(fr, step_clock) if c])) if clocks else None,
         }
     else:
         # randomized: 2 n_iter + 2 = 6 passes over X of 2 m n l flops each (K2 / K3 alternate); the
         # per-kernel split lives in profiles/ (rocprofv3 --kernel-trace of scripts/bench_cfg4.py)
         l = r + 20
         flops = 6 * 2.0 * m * n * l
-        out["roofline"] = {"bound": "mfma", "kernel": "K2 skinny + K3 gemm_tn, 6 passes over X",
+        out["roofline"] = {"bound": "mfma", "kernel": "K2 skinny16 (Y = X Q, fused Gram) + K3 gemm_tn (Z = X^T Y), 6 passes over X",
                            "achieved": flops * args.steps / dt / 1e12, "peak": PEAK_FP32_MFMA_TFLOPS,
                            "unit": "TFLOP/s", "frac": flops * args.steps / dt / 1e12 / PEAK_FP32_MFMA_TFLOPS,
                            "traffic": None, "flops_per_step": flops,
                            "note": "whole-step algorithmic rate of ONE rank's shard (per GPU; no per-launch "
                                    "events in the timed region)"}
+        # the phases of one more step, outside the timed region (every phase boundary synchronises)
+        ph = dsvd.svd_randomized(blocks, r, n_oversamples=20, n_iter=2, random_state=0, comm=comm, kern=kern, timings=True).info
+        out["stage_ms"] = {k: float(v) for k, v in ph.get("phase_ms", {}).items()}
+        out["stage_ms"]["total"] = float(ph["t_total"]) * 1e3
     if svd_type == "standard":
         # stage split of one more step, outside the timed region (the stage timers synchronise)
-        st = dsvd.svd_snapshots(blocks, r, comm=comm, kern=kern, timings=True).info
-        out["stage_ms"] = {k[2:]: float(st[k]) * 1e3 for k in ("t_gram", "t_eig", "t_project", "t_refine", "t_total")}
-        if "t_polish" in st:
-            out["stage_ms"]["polish (inside eig)"] = float(st["t_polish"]) * 1e3
+        # (the minimum of three calls per stage: a single call once showed a 41 ms `refine` on the
+        # driver's box where every other run has 2.3 ms -- a 208 MB allocation served by the driver
+        # instead of the caching allocator; all three calls are listed)
+        sts = [dsvd.svd_snapshots(blocks, r, comm=comm, kern=kern, timings=True).info for _ in range(3)]
+        keys = ["t_gram", "t_eig", "t_project", "t_refine", "t_total"] + (["t_polish"] if "t_polish" in sts[0] else [])
+        out["stage_ms"] = {k[2:]: float(min(st[k] for st in sts)) * 1e3 for k in keys}
+        out["stage_ms_calls"] = [{k[2:]: float(st[k]) * 1e3 for k in keys} for st in sts]
     out["kernel_ms_per_step"] = {k: float(np.sum(v)) / args.steps for k, v in by_name.items()}
     out["row_blocks"] = nblk
     out["svd_info"] = {k: (float(v) if isinstance(v, (int, float)) else v)
@@ -513,6 +551,16 @@ def main():
         out["calibration"] = calibrate(device, kern, blocks if svd_type == "standard" else None)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(blocks[0], r, kern, args.cpu_baseline_rows, m, args.cpu_baseline_full)
+        # The full-width sample SURVEY.md 8(d) asks for (all n columns: 17520 x 8760 at cfg2) costs ~7.4 x
+        # the half-width one (203.8 s against 27.8 s on the 128-thread box): taken by default when the
+        # half-width timing says it ends within ~4 minutes, so that the whole run stays inside the
+        # driver's limit; the half-width figures stay in the line next to it.
+        half = out["cpu_baseline"]
+        if (not args.cpu_baseline_full and args.workload == "cfg2" and os.environ.get("DMDX_BENCH_CPU_FULL", "1") != "0"
+                and args.cpu_baseline_rows is None and 7.5 * half["seconds"] <= 240.0):
+            full = cpu_baseline(blocks[0], r, kern, None, m, True)
+            full["half_width_sample"] = {k: half[k] for k in ("value", "seconds", "sample", "parity", "randomized") if k in half}
+            out["cpu_baseline"] = full
     if rank == 0 and world == 1 and not args.no_hard_spectrum and args.workload == "cfg2" and args.spectrum == "planted":
         del blocks
         kern.release_workspace()

@@ -54,6 +54,10 @@ SIGNATURES = {
     "dmdx_symm_skinny_f64": (C.c_int, [_p, _i64, _i64, _p, _i64, _i64, C.c_double, _p, _i64, _p, _sz, _p]),
     "dmdx_gemm_tn_f64_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "dmdx_gemm_tn_f64": (C.c_int, [_p, _i64, _p, _i64, _i64, _i64, _i64, _p, _i64, _p, _sz, _p]),
+    "dmdx_potrf_trtri_max_n": (C.c_int, []),
+    "dmdx_potrf_trtri_workspace_bytes": (_sz, [_i64]),
+    "dmdx_potrf_trtri_f64": (C.c_int, [_p, _i64, _i64, C.c_double, _p, _i64, _p, _i64, _p, _p, _sz, _p]),
+    "dmdx_gemm_nt_f64": (C.c_int, [_p, _i64, _i64, _i64, _p, _i64, _i64, _p, _i64, _p]),
     "dmdx_pack_triu_f64": (C.c_int, [_p, _i64, _i64, _p, _p]),
     "dmdx_unpack_triu_f64": (C.c_int, [_p, _i64, _p, _i64, _p]),
     "dmdx_exp_basis": (C.c_int, [_p, _p, _i64, _i64, _p, _p, C.c_int, _p]),

@@ -409,6 +409,52 @@ class HipKernels:
         _lib.check(rc, "dmdx_gemm_tn_f64")
         return Cm
 
+    # -- K10 / K11 --------------------------------------------------------------
+    @property
+    def chol_max_n(self) -> int:
+        return int(self._lib.dmdx_potrf_trtri_max_n())
+
+    def chol_inv(self, A: torch.Tensor, shift: float = 0.0, want_inv: bool = True):
+        """A + shift I = L L^T for a symmetric fp64 device matrix (n <= chol_max_n), one launch:
+        -> (L (n, n) lower, Linv (n, n) lower or None, info) with ``info`` a 3-vector of device
+        doubles: status (0 ok; j + 1 = first bad pivot, outputs finite but meaningless; -1 = the
+        launch could not synchronise), min and max of diag(L).  Nothing is read back here: the
+        caller queues what follows and looks at ``info`` once."""
+        if A.dim() != 2 or A.shape[0] != A.shape[1] or A.dtype != torch.float64 or not A.is_cuda:
+            raise _lib.DmdxError("chol_inv: A must be a square fp64 device matrix")
+        if A.stride(1) != 1:
+            A = A.contiguous()
+        n = A.shape[0]
+        L = torch.empty((n, n), dtype=torch.float64, device=A.device)
+        Linv = torch.empty((n, n), dtype=torch.float64, device=A.device) if want_inv else None
+        info = torch.empty(3, dtype=torch.float64, device=A.device)
+        ws = torch.empty(self._lib.dmdx_potrf_trtri_workspace_bytes(n), dtype=torch.uint8, device=A.device)
+        rc = self._timed("chol_inv", (n,), lambda: self._lib.dmdx_potrf_trtri_f64(
+            _ptr(A), n, A.stride(0), float(shift), _ptr(L), n, _ptr(Linv), n, _ptr(info), _ptr(ws), ws.numel(),
+            self._stream()
+        ))
+        _lib.check(rc, "dmdx_potrf_trtri_f64")
+        return L, Linv, info
+
+    def gemm_nt64(self, Q: torch.Tensor, Mt: torch.Tensor) -> torch.Tensor:
+        """Y = Q Mt^T for a tall fp64 device block Q (n, b1) and a small Mt (b2, b1): fp64 MFMA, one
+        launch.  Odd b1 / unaligned views go through the library GEMM."""
+        if Q.dtype != torch.float64 or Mt.dtype != torch.float64 or Q.dim() != 2 or Mt.dim() != 2 \
+                or Q.shape[1] != Mt.shape[1] or not (Q.is_cuda and Mt.is_cuda):
+            raise _lib.DmdxError("gemm_nt64: Q (n, b1) and Mt (b2, b1) must be fp64 device matrices")
+        n, b1 = Q.shape
+        b2 = Mt.shape[0]
+        ok = (b1 >= 2 and b1 % 2 == 0 and Q.stride(1) == 1 and Mt.stride(1) == 1 and Q.stride(0) % 2 == 0
+              and Mt.stride(0) % 2 == 0 and Q.data_ptr() % 16 == 0 and Mt.data_ptr() % 16 == 0 and n >= 1 and b2 >= 1)
+        if not ok:
+            return Q @ Mt.T
+        Y = torch.empty((n, b2), dtype=torch.float64, device=Q.device)
+        rc = self._timed("gemm_nt64", (n, b1, b2), lambda: self._lib.dmdx_gemm_nt_f64(
+            _ptr(Q), Q.stride(0), n, b1, _ptr(Mt), Mt.stride(0), b2, _ptr(Y), b2, self._stream()
+        ))
+        _lib.check(rc, "dmdx_gemm_nt_f64")
+        return Y
+
     # -- packed upper triangle (the Gram all-reduce of the row-sharded path) -----
     def pack_triu(self, A: torch.Tensor) -> torch.Tensor:
         """Upper triangle of a square fp64 device matrix, row by row: n (n + 1) / 2 doubles."""

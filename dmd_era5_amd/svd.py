@@ -59,20 +59,21 @@ class Comm:
     rank = 0
     exchanges = False   # whether the collectives are issued (TorchDistComm: world_size > 1)
     n_collectives = 0   # collectives issued so far (bench.py reports them per step)
+    timed = None        # TorchDistComm.start_timing(): list of (tag, bytes, start, stop) per collective
 
-    def allreduce_sum_(self, t: torch.Tensor) -> torch.Tensor:
+    def allreduce_sum_(self, t: torch.Tensor, tag: str = "allreduce") -> torch.Tensor:
         return t
 
-    def allgather(self, t: torch.Tensor) -> list[torch.Tensor]:
+    def allgather(self, t: torch.Tensor, tag: str = "allgather") -> list[torch.Tensor]:
         return [t]
 
-    def broadcast_(self, *tensors: torch.Tensor):
+    def broadcast_(self, *tensors: torch.Tensor, tag: str = "broadcast"):
         """Make rank 0's copy of small replicated results (eigenvectors, rotations)
         authoritative: every rank computes them from identical all-reduced inputs, but a
         last-bit or sign difference between devices would make the U shards inconsistent."""
         return tensors if len(tensors) != 1 else tensors[0]
 
-    def gather_to_root(self, t: torch.Tensor) -> list[torch.Tensor] | None:
+    def gather_to_root(self, t: torch.Tensor, tag: str = "gather") -> list[torch.Tensor] | None:
         """Every rank's tensor (shapes may differ in any dimension) as a list of HOST tensors on
         rank 0, None elsewhere: the result assembly for the NetCDF write -- U, the row means
         and, if asked for, X leave the devices only here."""
@@ -94,27 +95,63 @@ class TorchDistComm(Comm):
         # exercised on a one-GPU box (tests/test_gpu_pipeline.py); never set by the product
         self.exchanges = self.world_size > 1 or os.environ.get("DMDX_COMM_FORCE") == "1"
 
-    def allreduce_sum_(self, t: torch.Tensor) -> torch.Tensor:
+    # -- per-collective wall time (bench.py: `collective_ms`; so that the first multi-GPU run explains
+    # itself).  Device tensors: a HIP event pair on the current stream around the call (the call
+    # returns once the collective is enqueued; its completion is ordered before the second event);
+    # host tensors (gloo): the host clock.
+    def start_timing(self) -> None:
+        self.timed = []
+
+    def stop_timing(self) -> dict:
+        """-> {tag: {"calls", "ms", "bytes"}} of everything issued since start_timing()."""
+        out: dict = {}
+        for tag, nbytes, t0, t1 in (self.timed or []):
+            ms = t0.elapsed_time(t1) if hasattr(t0, "elapsed_time") else (t1 - t0) * 1e3
+            d = out.setdefault(tag, {"calls": 0, "ms": 0.0, "bytes": 0})
+            d["calls"] += 1
+            d["ms"] += float(ms)
+            d["bytes"] += int(nbytes)
+        self.timed = None
+        return out
+
+    def _run(self, tag: str, tensors, fn):
+        if self.timed is None:
+            return fn()
+        nbytes = sum(int(t.numel()) * t.element_size() for t in tensors)
+        if tensors and tensors[0].is_cuda:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = fn()
+            e1.record()
+        else:
+            e0 = time.perf_counter()
+            r = fn()
+            e1 = time.perf_counter()
+        self.timed.append((tag, nbytes, e0, e1))
+        return r
+
+    def allreduce_sum_(self, t: torch.Tensor, tag: str = "allreduce") -> torch.Tensor:
         if self.exchanges:
             self.n_collectives += 1
-            self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self._group)
+            self._run(tag, [t], lambda: self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self._group))
         return t
 
-    def allgather(self, t: torch.Tensor) -> list[torch.Tensor]:
+    def allgather(self, t: torch.Tensor, tag: str = "allgather") -> list[torch.Tensor]:
         if not self.exchanges:
             return [t]
         out = [torch.empty_like(t) for _ in range(self.world_size)]
         self.n_collectives += 1
-        self._dist.all_gather(out, t.contiguous(), group=self._group)
+        tc = t.contiguous()
+        self._run(tag, [tc], lambda: self._dist.all_gather(out, tc, group=self._group))
         return out
 
-    def broadcast_(self, *tensors: torch.Tensor):
+    def broadcast_(self, *tensors: torch.Tensor, tag: str = "broadcast"):
         if self.exchanges:
             if len(tensors) > 1 and len({(t.dtype, t.device) for t in tensors}) == 1:
                 # ONE collective for the lot (eigenvalues + eigenvectors, rotation + values)
                 flat = torch.cat([t.reshape(-1) for t in tensors])
                 self.n_collectives += 1
-                self._dist.broadcast(flat, src=0, group=self._group)
+                self._run(tag, [flat], lambda: self._dist.broadcast(flat, src=0, group=self._group))
                 off = 0
                 for t in tensors:
                     t.copy_(flat[off:off + t.numel()].view(t.shape))
@@ -122,14 +159,21 @@ class TorchDistComm(Comm):
             else:
                 for t in tensors:
                     self.n_collectives += 1
-                    self._dist.broadcast(t, src=0, group=self._group)
+                    self._run(tag, [t], lambda t=t: self._dist.broadcast(t, src=0, group=self._group))
         return tensors if len(tensors) != 1 else tensors[0]
 
-    def gather_to_root(self, t: torch.Tensor) -> list[torch.Tensor] | None:
+    GATHER_BUDGET = 1 << 30   # bytes of receive buffer on the root per collective
+
+    def gather_to_root(self, t: torch.Tensor, tag: str = "gather") -> list[torch.Tensor] | None:
+        """One `gather` collective per GATHER_BUDGET of receive buffer instead of world_size - 1
+        serial send / recv pairs (round 3): every rank's tensor is flattened and padded to the
+        longest; the root receives all pieces of a chunk at once (RCCL moves device buffers, gloo
+        host buffers) and copies them into its host tensors.  U of a cfg3 shard (1.6 GB per rank) is
+        13 collectives at N = 8; a `save_data_matrix` X never needs more than the budget on the
+        root's device."""
         if not self.exchanges:
             return [t.cpu()]
         dist = self._dist
-        # gloo moves host memory, RCCL device memory: stage accordingly
         on_host = dist.get_backend(self._group) == "gloo"
         t = t.contiguous()
         if t.dim() > 8:
@@ -137,18 +181,30 @@ class TorchDistComm(Comm):
         dims = torch.full((9,), -1, dtype=torch.int64, device="cpu" if on_host else t.device)
         dims[0] = t.dim()
         dims[1:1 + t.dim()] = torch.tensor(t.shape, dtype=torch.int64)
-        shapes = [tuple(int(v) for v in d[1:1 + int(d[0])].tolist()) for d in self.allgather(dims)]
-        if self.rank != 0:
-            if t.numel():
-                dist.send(t.cpu() if on_host else t, dst=0, group=self._group)
+        shapes = [tuple(int(v) for v in d[1:1 + int(d[0])].tolist()) for d in self.allgather(dims, tag=tag + "_shapes")]
+        counts = [int(np.prod(sh)) if len(sh) else 1 for sh in shapes]
+        longest = max(counts)
+        root = self.rank == 0
+        host = [torch.empty(c, dtype=t.dtype) for c in counts] if root else None
+        flat = t.reshape(-1).cpu() if on_host else t.reshape(-1)
+        dev = flat.device
+        chunk = max(1, self.GATHER_BUDGET // (self.world_size * t.element_size()))
+        for off in range(0, longest, chunk):
+            n = min(chunk, longest - off)
+            piece = flat[off:off + n]
+            if piece.numel() < n:        # shorter ranks pad (the root drops the padding)
+                piece = torch.cat([piece, torch.zeros(n - piece.numel(), dtype=flat.dtype, device=dev)])
+            recv = [torch.empty(n, dtype=flat.dtype, device=dev) for _ in range(self.world_size)] if root else None
+            self.n_collectives += 1
+            self._run(tag, [piece], lambda: dist.gather(piece.contiguous(), recv, dst=0, group=self._group))
+            if root:
+                for r in range(self.world_size):
+                    m = min(n, counts[r] - off)
+                    if m > 0:
+                        host[r][off:off + m] = recv[r][:m].cpu()
+        if not root:
             return None
-        out = [t.cpu()]
-        for r in range(1, self.world_size):
-            buf = torch.empty(shapes[r], dtype=t.dtype, device="cpu" if on_host else t.device)
-            if buf.numel():
-                dist.recv(buf, src=r, group=self._group)
-            out.append(buf.cpu())
-        return out
+        return [host[r].reshape(shapes[r]) for r in range(self.world_size)]
 
 
 @dataclass
@@ -190,10 +246,45 @@ def _tn(kern, A: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
     return f(A, B) if f is not None else A.T @ B
 
 
+def _chol(kern, A: torch.Tensor, shift=0.0, want_inv: bool = True):
+    """A + shift I = L L^T for a small symmetric fp64 matrix -> (L, Linv or None, info) with ``info`` a
+    3-vector of device doubles (status: 0 ok; min, max of diag(L)) that the caller reads ONCE,
+    after queueing what follows.  One launch of K10 (kernels.chol_inv: Cholesky + triangular
+    inverse, n <= 1024) when the provider has it -- rocSOLVER's potrf / trtri are launch-rate bound
+    at these sizes and cost 0.3-0.8 s of library start-up in a CLI process --, else the library."""
+    n = A.shape[0]
+    f = getattr(kern, "chol_inv", None) if kern is not None else None
+    if f is not None and A.is_cuda and n <= getattr(kern, "chol_max_n", 0):
+        return f(A, shift=float(shift), want_inv=want_inv)
+    As = A if (isinstance(shift, float) and shift == 0.0) else A + shift * torch.eye(n, dtype=A.dtype, device=A.device)
+    L, err = torch.linalg.cholesky_ex(As)
+    diag = torch.diagonal(L)
+    fin = torch.isfinite(diag).all()
+    info = torch.stack([torch.where(fin, err.to(A.dtype).reshape(()), torch.ones((), dtype=A.dtype, device=A.device)),
+                        diag.min(), diag.max()])
+    Linv = torch.linalg.solve_triangular(L, torch.eye(n, dtype=A.dtype, device=A.device), upper=False) if want_inv else None
+    return L, Linv, info
+
+
+def _chol_ok(info) -> bool:
+    """One read-back of a factorisation's status (see :func:`_chol`)."""
+    st, dmin, dmax = info.tolist()
+    return st == 0.0 and math.isfinite(dmin) and math.isfinite(dmax) and dmin > 0.0
+
+
+def _apply_nt(kern, Q: torch.Tensor, Mt: torch.Tensor) -> torch.Tensor:
+    """Q Mt^T for a tall fp64 block: K11 (fp64 MFMA, one launch) when the provider has it."""
+    f = getattr(kern, "gemm_nt64", None) if kern is not None else None
+    if f is not None and Q.is_cuda:
+        return f(Q if Q.stride(1) == 1 else Q.contiguous(), Mt if Mt.stride(1) == 1 else Mt.contiguous())
+    return Q @ Mt.T
+
+
 def _orth(Y: torch.Tensor, rounds: int = 2, _shifted: bool = False, kern=None) -> torch.Tensor:
     """Orthonormal basis of the columns of a tall fp64 block.  CholeskyQR2 (two rounds of
-    Gram -> Cholesky -> triangular solve: three small GEMM-type calls, ~1 ms at 8760 x 210)
-    instead of Householder QR (rocSOLVER geqrf+orgqr: ~9 ms).  A block too ill-conditioned for
+    Gram (K9) -> Cholesky + triangular inverse (K10) -> Q L^-T (K11): three launches of our own per
+    round; round 2 went through rocSOLVER potrf + rocBLAS trsm, Householder QR costs ~9 ms).  A
+    block too ill-conditioned for
     the plain Gram route (cond > ~1e8: G times a random block of a low-rank + noise matrix spans
     lambda_1 / lambda_noise) first gets ONE *shifted* round (Fukaya et al. 2020: factor
     Y^T Y + s I, s ~ 1e-11 |Y|^2, which caps the conditioning of what the plain rounds then see);
@@ -203,19 +294,17 @@ def _orth(Y: torch.Tensor, rounds: int = 2, _shifted: bool = False, kern=None) -
     Q = Y
     for it in range(rounds):
         G = _tn(kern, Q, Q)
-        L, err = torch.linalg.cholesky_ex(G)
-        # the triangular solve is queued BEFORE the host looks at the factorisation's status (one
-        # read-back of one flag): the device works on while the host waits for it
-        failed = torch.logical_or(err != 0, ~torch.isfinite(torch.diagonal(L)).all())
-        Qn = torch.linalg.solve_triangular(L, Q.T, upper=False).T
-        if bool(failed):
+        L, Linv, info = _chol(kern, G)
+        # the product is queued BEFORE the host looks at the factorisation's status (one read-back
+        # of three numbers): the device works on while the host waits for it
+        Qn = _apply_nt(kern, Q, Linv)
+        if not _chol_ok(info):
             if it == 0 and not _shifted:
-                tr = torch.diagonal(G).sum()
-                eye = torch.eye(G.shape[0], dtype=G.dtype, device=G.device)
+                tr = float(torch.diagonal(G).sum())
                 for rel in (1e-11, 1e-8):
-                    L, err = torch.linalg.cholesky_ex(G + (rel * tr) * eye)
-                    if int(err) == 0 and bool(torch.isfinite(L).all()):
-                        Qs = torch.linalg.solve_triangular(L, Q.T, upper=False).T
+                    L, Linv, info = _chol(kern, G, shift=rel * tr)
+                    if _chol_ok(info) and bool(torch.isfinite(Linv).all()):
+                        Qs = _apply_nt(kern, Q, Linv)
                         return _orth(Qs, rounds=max(rounds, 2) + (1 if rel == 1e-8 else 0), _shifted=True, kern=kern)
             Qh, _ = torch.linalg.qr(Y, mode="reduced")
             return Qh
@@ -247,11 +336,13 @@ def _eigh_desc(T: torch.Tensor, kern=None):
             pass
     elif kern is not None and n <= getattr(kern, "svd_jacobi_max_n", 0):
         shift = 0.0
-        L, err = torch.linalg.cholesky_ex(T)
-        if int(err) != 0 or not bool(torch.isfinite(torch.diagonal(L)).all()):
+        L, _, info = _chol(kern, T, want_inv=False)
+        ok = _chol_ok(info)
+        if not ok:
             shift = 1e-8 * float(torch.diagonal(T).abs().mean())
-            L, err = torch.linalg.cholesky_ex(T + shift * torch.eye(n, dtype=T.dtype, device=T.device))
-        if int(err) == 0 and bool(torch.isfinite(torch.diagonal(L)).all()):
+            L, _, info = _chol(kern, T, shift=shift, want_inv=False)
+            ok = _chol_ok(info)
+        if ok:
             try:
                 lam, Z = _jacobi_pd_eigh(L.T.contiguous(), kern)
                 return lam - shift, Z
@@ -306,8 +397,8 @@ def _graded_eigh(s0: torch.Tensor, Mm: torch.Tensor, kern=None):
     if lg == 0:
         return _eigh_desc(T, kern)
     Mg = Mm[g][:, g]
-    L, err = torch.linalg.cholesky_ex(0.5 * (Mg + Mg.T))
-    if int(err.item()) != 0 or not bool(torch.isfinite(L).all()):
+    L, _, info = _chol(kern, 0.5 * (Mg + Mg.T), want_inv=False)
+    if not _chol_ok(info) or not bool(torch.isfinite(L).all()):
         return _eigh_desc(T, kern)
     Zg = None
     if kern is not None and 2 <= lg <= getattr(kern, "svd_jacobi_max_n", 0):
@@ -335,6 +426,9 @@ def _graded_eigh(s0: torch.Tensor, Mm: torch.Tensor, kern=None):
 # takes ~1.0 ms at n = 8760 for any block up to 312 columns (rocBLAS, tall-skinny), CholeskyQR2
 # ~0.9 ms at 77 columns / 1.2 at 124 / 2.5 at 312; the library's full solver (syevd) 816 / 142 /
 # 50 ms at n = 8760 / 4000 / 2000.
+_FULL_EIGH_MAX_N = 2048   # above it the filtered iteration never hands over to the library's full solver (50 ms at 2048, 816 ms at 8760)
+
+
 def _full_eigh_ms(n: int) -> float:
     return 816.0 * (n / 8760.0) ** 2
 
@@ -466,21 +560,32 @@ def top_eigh(G: torch.Tensor, l: int, method: str = "auto", tol: float = 1e-9,
     # the old ones is known from the Rayleigh-Ritz step, so this costs two products.
     b2 = min(n // 3, max(b, 2 * l)) & ~1
     if b2 > b:
+        # NO Rayleigh-Ritz step on the widened block before the first filter pass (round 3: it cost
+        # 12 ms of 65 at rank 200 -- a 500 x 500 eigenproblem -- to learn one number, the cut).  The
+        # widened block [Q, W] is orthonormal as it stands; the wanted pairs and their residuals are
+        # those of the narrow block; the cut -- the smallest Ritz value of the block, below which
+        # the filter damps -- is taken from the small matrix W^T G W alone: its smallest eigenvalue
+        # is >= the block's smallest Ritz value (interlacing) and far below theta_l, and any cut below
+        # theta_l filters correctly (a higher cut only converges a little more slowly).
         W = gq(torch.randn((n, b2 - b), dtype=torch.float64, generator=gen, device=G.device))
         for _ in range(2):
             W = W - Q @ _tn(kern, Q, W)
         W = _orth(W, kern=kern)
-        th, Q, GQ, resv = ritz(torch.cat([Q, W], dim=1), torch.cat([GQ, gq(W)], dim=1))
+        GW = gq(W)
         products += 2
+        Tw = _tn(kern, W, GW)
+        thw, _ = _eigh_desc(0.5 * (Tw + Tw.T), kern)
+        cut_w = torch.minimum(thw[-1], th[b - 1]).clamp_min(0.0)
+        Q = torch.cat([Q, W], dim=1)
+        th = torch.cat([th, cut_w.expand(b2 - b)])
+        resv = torch.cat([resv, torch.zeros(b2 - b, dtype=resv.dtype, device=resv.device)])
         b = b2
-        res = float(resv[:l].max())
-        if res <= tol:
-            return done(th, Q, res, "power", 2)
 
     max_deg = 24
     full_ms = _full_eigh_ms(n)
     step_ms = _filter_step_ms(n, b)
     spent = 0
+    capped = 0
     degrees: list[int] = []
     if info is not None:
         info["eig_degrees"] = degrees
@@ -493,10 +598,25 @@ def top_eigh(G: torch.Tensor, l: int, method: str = "auto", tol: float = 1e-9,
         x = 2.0 * thl[j] / cut - 1.0 if cut > 0.0 else math.inf
         rho = x + math.sqrt(max(x * x - 1.0, 0.0)) if math.isfinite(x) else math.inf
         need = math.log(3.0 * rl[j] / tol) / math.log(rho) if rho > 1.0 + 1e-12 else math.inf
-        if not math.isfinite(need) or need * step_ms > full_ms or spent * step_ms > 3.0 * full_ms:
+        hopeless = not math.isfinite(need) or need * step_ms > full_ms or spent * step_ms > 3.0 * full_ms
+        if hopeless:
             if info is not None:
                 info["eig_cheb_forecast_steps"] = float(min(need, 1e9))
-            break
+            if n <= _FULL_EIGH_MAX_N:
+                break
+            # A spectrum with no gap anywhere near the wanted rank (a numerical multiple of the
+            # identity: every eigenvalue within 0.1 %) at a size where the library's full solver
+            # costs most of a second (828 ms at n = 8760, more than the Gram itself): no polynomial
+            # converges there, and nothing is lost by not converging -- every orthonormal block
+            # captures the same energy to the spread of the spectrum.  Two more passes of full
+            # degree, then the Ritz pairs are returned with their residual stated (round 3).
+            if capped >= 2:
+                if info is not None:
+                    info["eig_warning"] = (f"flat spectrum: residual {res:.2e} lambda_1 > tol {tol:.0e} after {products} products; "
+                                           "Ritz values are accurate to that residual")
+                return done(th, Q, res, "cheb-capped", it)
+            capped += 1
+            need = float(max_deg)
         # (the first forecast rests on the Ritz values of a freshly widened block: capped lower)
         deg = int(min(max_deg if it else 10, max(2, math.ceil(_CHEB_SAFETY * need) + 1)))
         degrees.append(deg)
@@ -581,9 +701,9 @@ def _gram_blocks(blocks, kern, comm: Comm) -> torch.Tensor:
     G = kern.syrk_blocks(blocks) if len(blocks) > 1 else kern.syrk(blocks[0])
     n = G.shape[0]
     if comm.exchanges and n >= 64 and hasattr(kern, "pack_triu"):
-        packed = comm.allreduce_sum_(kern.pack_triu(G))
+        packed = comm.allreduce_sum_(kern.pack_triu(G), tag="gram_allreduce" if n >= 1024 else "small_gram_allreduce")
         return kern.unpack_triu(packed, n, out=G)
-    return comm.allreduce_sum_(G)
+    return comm.allreduce_sum_(G, tag="gram_allreduce" if n >= 1024 else "small_gram_allreduce")
 
 
 def _gemm_tn_blocks(Ablocks, Bblocks, kern, comm: Comm) -> torch.Tensor:
@@ -591,7 +711,7 @@ def _gemm_tn_blocks(Ablocks, Bblocks, kern, comm: Comm) -> torch.Tensor:
         C = kern.gemm_tn_blocks(list(Ablocks), list(Bblocks))
     else:
         C = kern.gemm_tn(Ablocks[0], Bblocks[0])
-    return comm.allreduce_sum_(C)
+    return comm.allreduce_sum_(C, tag="xty_allreduce")
 
 
 def _project_blocks(kern, Xblocks, Wt: torch.Tensor, d: int, whole: torch.Tensor | None = None):
@@ -642,7 +762,7 @@ def _sign_flip(Ublocks, Vh: torch.Tensor, comm: Comm, kern):
     if comm.exchanges:
         # ONE exchange per rank, whatever its number of row blocks (ranks may hold different numbers
         # of blocks: bands of different height, streamed pieces)
-        allv = torch.stack(comm.allgather(val.contiguous()), dim=0)  # (world, k)
+        allv = torch.stack(comm.allgather(val.contiguous(), tag="sign_allgather"), dim=0)  # (world, k)
         pick = allv.abs().argmax(dim=0, keepdim=True)
         val = allv.gather(0, pick).squeeze(0)
     sign = torch.where(val < 0, -torch.ones_like(val), torch.ones_like(val))
@@ -706,7 +826,7 @@ def _shard_stats(blocks, comm: Comm, delay: int, with_mean: bool) -> dict:
         v[2] *= scale2          # different amax must add like with like
     v[3] = float(sum(B.shape[1] for B in blocks) * delay)
     if comm.exchanges:
-        allv = torch.stack(comm.allgather(v))
+        allv = torch.stack(comm.allgather(v, tag="stats_allgather"))
         v = torch.cat([allv[:, :1].max(dim=0).values, allv[:, 1:].sum(dim=0)])
     amax, mean2, var, rows = v.tolist()
     return {"amax": amax, "mean2": mean2, "var": var, "rows": int(round(rows))}
@@ -771,7 +891,7 @@ def _eig_mean_deflated(G, w, musq, delay: int, l: int, eig_method: str, info: di
     # leading eigenvectors of Gd, projected off q (a rank-deficient Gd returns arbitrary
     # null vectors, q among them); the projected matrix comes from products, not from lam_d.
     Bs = torch.cat([z[:, None] / torch.linalg.vector_norm(z).clamp_min(1e-300), Vd], dim=1)
-    Bs = _orth(Bs - torch.outer(q, q @ Bs))
+    Bs = _orth(Bs - torch.outer(q, q @ Bs), kern=kern)
     c = Bs.T @ z
     T11 = Bs.T @ (Gd @ Bs) + torch.outer(c, c) / alpha
     T = torch.zeros((Bs.shape[1] + 1,) * 2, dtype=torch.float64, device=dev)
@@ -853,7 +973,7 @@ def svd_snapshots(Xt, n_components: int, delay: int = 1, oversample: int | None 
             lam, V = top_eigh(G, l, method=eig_method, info=info, kern=kern)
         else:
             lam, V, lam_d, l = _eig_mean_deflated(G, w, musq, delay, l, eig_method, info, kern)
-        comm.broadcast_(lam, V)
+        comm.broadcast_(lam, V, tag="eig_broadcast")
         lam1 = lam[0].clamp_min(1e-300)
         ref = lam[1] if (mus is not None and lam.numel() > 1) else lam1   # the deflated scale
         steep = float(lam[min(k, lam.numel()) - 1]) < 1e-7 * float(ref)
@@ -880,7 +1000,7 @@ def svd_snapshots(Xt, n_components: int, delay: int = 1, oversample: int | None 
                 comm.allreduce_sum_(my)
                 Zt = Zt + my[:, None]
             Zn = Zt / torch.linalg.vector_norm(Zt, dim=1, keepdim=True).clamp_min(1e-300)
-            V = _orth(Zn.T.contiguous())   # (columns span ~s_j^2: normalised first, CholeskyQR is not scale invariant)
+            V = _orth(Zn.T.contiguous(), kern=kern)   # (columns span ~s_j^2: normalised first, CholeskyQR is not scale invariant)
             comm.broadcast_(V)
             lam = torch.ones_like(lam)                                # no S^-1 scaling of E V below
             info["polished"] = True
@@ -1053,7 +1173,7 @@ def svd_snapshots_streaming(pieces, n_components: int, rows_global: int, delay: 
             comm.allreduce_sum_(my)
             Zt = Zt + my[:, None]
         Zn = Zt / torch.linalg.vector_norm(Zt, dim=1, keepdim=True).clamp_min(1e-300)
-        V = _orth(Zn.T.contiguous())
+        V = _orth(Zn.T.contiguous(), kern=kern)
         comm.broadcast_(V)
         lam = torch.ones_like(lam)
         info["polished"] = True
@@ -1138,7 +1258,7 @@ def svd_randomized_streaming(pieces, n_components: int, rows_global: int, n_time
         if not bool(torch.isfinite(Z).all()):
             raise np.linalg.LinAlgError("SVD did not converge")
         Zn = Z / torch.linalg.vector_norm(Z, dim=1, keepdim=True).clamp_min(1e-300)
-        Qt = comm.broadcast_(_orth(Zn.T.contiguous()).T.contiguous().to(torch.float32))
+        Qt = comm.broadcast_(_orth(Zn.T.contiguous(), kern=kern).T.contiguous().to(torch.float32))
     Yp, bounds = [], [0]
     for blocks in pieces():
         if Qt is None:
@@ -1177,7 +1297,7 @@ def _project_with_gram(kern, Eb, Qp, comm: Comm):
     if l <= getattr(kern, "skinny_gram_max_l", 0):
         G0 = torch.zeros((l, l), dtype=torch.float64, device=Eb[0].device)
         Yb = [kern.skinny(E, Qp, gram=G0) for E in Eb]
-        return Yb, comm.allreduce_sum_(G0)
+        return Yb, comm.allreduce_sum_(G0, tag="small_gram_allreduce")
     return [kern.skinny(E, Qp) for E in Eb], None
 
 
@@ -1191,34 +1311,20 @@ def _cholqr(Yb, comm: Comm, kern, passes: int = 1, G0: torch.Tensor | None = Non
     its pivots collapse) the pass is redone as *shifted* CholeskyQR (Fukaya et al. 2020):
     factor G + s I with s ~ 1e-6 trace(G), which caps the conditioning of Y R^-1 at ~1e3, and one
     extra plain pass is appended to restore orthonormality.  The span of Y is unchanged."""
-    l = Yb[0].shape[0]
-    eye = torch.eye(l, dtype=torch.float64, device=Yb[0].device)
     todo, done = passes, 0
     while todo > 0 and done < passes + 3:
         done += 1
         todo -= 1
         G = G0 if (G0 is not None and done == 1) else _gram_blocks(Yb, kern, comm)   # G0: fused into the K2 launches
-        G = 0.5 * (G + G.T)
-        L, err = torch.linalg.cholesky_ex(G)
-        diag = torch.diagonal(L)
-        # (one read-back for the three checks: every host round trip is a bubble in the launch stream)
-        bad = bool(torch.logical_or(torch.logical_or(err != 0, ~torch.isfinite(diag).all()),
-                                    diag.min() < 1e-4 * diag.max()))
-        if bad:
-            # (the Gram of fp32 products can be indefinite by more than 1e-6 of its trace --
-            # identical values accumulate their rounding coherently -- so the shift escalates)
-            tr = torch.diagonal(G).sum()
-            if float(tr) == 0.0 and bool(torch.isfinite(G).all()):
-                return Yb      # Y is exactly zero (X = 0): nothing to orthonormalise, s comes out 0
-            for rel in (1e-6, 3e-5, 1e-3, 3e-2):
-                L, err = torch.linalg.cholesky_ex(G + (rel * tr) * eye)
-                if int(err) == 0 and bool(torch.isfinite(torch.diagonal(L)).all()):
-                    break
-            else:
-                raise np.linalg.LinAlgError("CholeskyQR: the Gram matrix of the range-finder block is not finite")
+        # (the Gram of fp32 products can be indefinite by more than 1e-6 of its trace -- identical
+        # values accumulate their rounding coherently -- so the shift escalates: _chol_rinv)
+        fac = _chol_rinv(G, comm, kern)
+        if fac is None:
+            return Yb      # Y is exactly zero (X = 0): nothing to orthonormalise, s comes out 0
+        Rinv, shifted, _ = fac
+        if shifted:
             todo += 1
-        Rinv = torch.linalg.solve_triangular(L.T, eye, upper=True)  # R = L^T
-        Rt = _pitched(kern, comm.broadcast_(Rinv.T.contiguous().to(torch.float32)))
+        Rt = _pitched(kern, Rinv.T.contiguous().to(torch.float32))
         # block by block, dropping each input as soon as its output exists: the peak stays at one
         # m x l matrix + one block instead of two matrices (13.7 GB each at cfg4, next to 227 GB of X)
         # (the caller's list is overwritten in place -- it is consumed by this function)
@@ -1227,40 +1333,37 @@ def _cholqr(Yb, comm: Comm, kern, passes: int = 1, G0: torch.Tensor | None = Non
     return Yb
 
 
-def _chol_rinv(G: torch.Tensor, comm: Comm):
+def _chol_rinv(G: torch.Tensor, comm: Comm, kern=None):
     """R^-1 (upper triangular, fp64) of the Cholesky factorisation G = R^T R of the Gram matrix of a
     tall block Y, plus how far it can be trusted: -> (Rinv, shifted, spread) with ``spread`` =
     min / max of R's diagonal (~ 1 / cond(Y)).  The Gram of fp32 products of an oversampled
     range-finder block can be numerically indefinite; then G + s I is factored instead with the
     smallest s of an escalating list that works (shifted CholeskyQR, Fukaya et al. 2020: Y R^-1 is
     then not orthonormal but has a condition number <= ~1e3) and ``shifted`` is True.  None if Y is
-    exactly zero (X = 0).  Rank 0's factor is made authoritative (one small broadcast)."""
-    l = G.shape[0]
-    eye = torch.eye(l, dtype=torch.float64, device=G.device)
+    exactly zero (X = 0).  Rank 0's factor is made authoritative (one small broadcast).
+    One launch of K10 per factorisation (Cholesky + triangular inverse), one read-back of its status."""
     G = 0.5 * (G + G.T)
-    L, err = torch.linalg.cholesky_ex(G)
-    diag = torch.diagonal(L)
-    # (one read-back for the three checks: every host round trip is a bubble in the launch stream)
-    st = torch.stack([(err != 0).double().reshape(()), (~torch.isfinite(diag).all()).double(),
-                      diag.min() / diag.max().clamp_min(1e-300)]).tolist()
-    bad = st[0] != 0.0 or st[1] != 0.0 or not (st[2] >= 1e-4)
+    L, Linv, info = _chol(kern, G)
+    st, dmin, dmax = info.tolist()
+    spread = dmin / max(dmax, 1e-300) if (math.isfinite(dmin) and math.isfinite(dmax)) else 0.0
+    bad = st != 0.0 or not (spread >= 1e-4)
     shifted = False
     if bad:
-        tr = torch.diagonal(G).sum()
-        if float(tr) == 0.0 and bool(torch.isfinite(G).all()):
+        tr = float(torch.diagonal(G).sum())
+        if tr == 0.0 and bool(torch.isfinite(G).all()):
             return None
         for rel in (1e-6, 3e-5, 1e-3, 3e-2):
-            L, err = torch.linalg.cholesky_ex(G + (rel * tr) * eye)
-            if int(err) == 0 and bool(torch.isfinite(torch.diagonal(L)).all()):
+            L, Linv, info = _chol(kern, G, shift=rel * tr)
+            st, dmin, dmax = info.tolist()
+            if st == 0.0 and math.isfinite(dmin) and math.isfinite(dmax) and dmin > 0.0:
                 break
         else:
             raise np.linalg.LinAlgError("CholeskyQR: the Gram matrix of the range-finder block is not finite")
         shifted = True
-        diag = torch.diagonal(L)
-        st[2] = float(diag.min() / diag.max().clamp_min(1e-300))
-    Rinv = torch.linalg.solve_triangular(L.T, eye, upper=True).contiguous()   # R = L^T
+        spread = dmin / max(dmax, 1e-300)
+    Rinv = Linv.T.contiguous()   # R = L^T, R^-1 = (L^-1)^T
     comm.broadcast_(Rinv)
-    return Rinv, shifted, float(st[2])
+    return Rinv, shifted, float(spread)
 
 
 def resolve_n_iter(n_components: int, m: int, n: int, n_iter="auto") -> int:
@@ -1343,7 +1446,7 @@ def svd_randomized(Xt, n_components: int, delay: int = 1, n_oversamples: int = 1
             if G0 is None:
                 G0 = _gram_blocks(Yb, kern, comm)
             phase("k2")
-            fac = _chol_rinv(G0, comm)
+            fac = _chol_rinv(G0, comm, kern)
             phase("small")
         else:
             Yb, fac = [kern.skinny(E, Qp) for E in Eb], None
@@ -1372,7 +1475,7 @@ def svd_randomized(Xt, n_components: int, delay: int = 1, n_oversamples: int = 1
     fused = int(G.shape[0]) <= getattr(kern, "skinny_gram_max_l", 0)
     Rlast = None
     for explicit in range(4):
-        fac = _chol_rinv(G, comm)
+        fac = _chol_rinv(G, comm, kern)
         if fac is None:                                    # Y is exactly zero (X = 0): s comes out 0
             break
         Rinv, shifted, spread = fac
@@ -1383,7 +1486,7 @@ def svd_randomized(Xt, n_components: int, delay: int = 1, n_oversamples: int = 1
         G = torch.zeros_like(G) if fused else None
         for i in range(len(Yb)):                           # Y_{j+1} = Y_j R_j^-1, block by block, Gram fused in
             Yb[i] = kern.skinny(Yb[i], Rt, gram=G) if fused else kern.skinny(Yb[i], Rt)
-        G = comm.allreduce_sum_(G) if fused else _gram_blocks(Yb, kern, comm)
+        G = comm.allreduce_sum_(G, tag="small_gram_allreduce") if fused else _gram_blocks(Yb, kern, comm)
     info["cholqr_explicit_passes"] = explicit
     phase("cholqr")
     Qmb = Yb

@@ -184,6 +184,30 @@ int dmdx_gemm_tn_f64(const double* A, int64_t lda, const double* B, int64_t ldb,
                      int64_t b1, int64_t b2, double* C, int64_t ldc,
                      void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- K10: Cholesky factor and its inverse of a small symmetric positive definite fp64 matrix, one launch --
+ * A (n x n, lda, row-major; only the lower triangle is read), n <= dmdx_potrf_trtri_max_n() (1024):
+ * A + shift I = L L^T, L (n x n, ldl) lower triangular (zeros above), Linv (n x n, ldi, nullable) = L^-1
+ * (lower triangular).  info: 3 device doubles -- [0] status: 0 ok, j + 1 = first non-positive or
+ * non-finite pivot (it is replaced by 1 and the factorisation goes on, so the outputs stay finite: the
+ * caller shifts and retries), -1 = the workgroups of the launch could not synchronise;
+ * [1] / [2] = min / max of diag(L) (~ 1 / cond).  One workgroup per 32-row block row (<= 32), one
+ * grid barrier per block column (counter in the workspace: the launch must be co-resident).
+ * Replaces LAPACK potrf + trtri / trsm behind the CholeskyQR rounds (the LU / QR normalisers of
+ * sklearn's randomized_svd, extmath.py:349-355, era5_svd.py:258) and the Cholesky factors fed to the
+ * Jacobi kernel (part of np.linalg.svd, era5_svd.py:251). */
+int dmdx_potrf_trtri_max_n(void);
+size_t dmdx_potrf_trtri_workspace_bytes(int64_t n);
+int dmdx_potrf_trtri_f64(const double* A, int64_t n, int64_t lda, double shift, double* L, int64_t ldl,
+                         double* Linv, int64_t ldi, double* info, void* workspace, size_t workspace_bytes,
+                         void* stream);
+
+/* ---- K11: Y = Q Mt^T for a tall fp64 block Q (n x b1, ldq) and a small Mt (b2 x b1, ldm), Y n x b2 (ldy),
+ * all row-major: Q L^-T of a CholeskyQR round (Mt = L^-1 from K10) and S Z of a Rayleigh-Ritz step
+ * (Mt = Z^T as K7L returns it).  fp64 MFMA, operands straight from global memory.  b1, ldq, ldm even;
+ * Q, Mt 16-byte aligned; Y must not alias an input. */
+int dmdx_gemm_nt_f64(const double* Q, int64_t ldq, int64_t n, int64_t b1, const double* Mt, int64_t ldm,
+                     int64_t b2, double* Y, int64_t ldy, void* stream);
+
 /* ---- upper triangle of a symmetric fp64 matrix <-> packed row by row ---------------------
  * packed[i (2n - i + 1) / 2 + (j - i)] = A[i][j], j >= i: what the Gram all-reduce of the
  * row-sharded path moves (n (n + 1) / 2 doubles instead of n^2).  unpack writes both triangles. */

@@ -953,3 +953,80 @@ def test_constant_matrix(typ):
     assert abs(s[0] / (3.5 * np.sqrt(m * n)) - 1) < 5e-6      # sklearn's fp32 answer is off by 2.4e-6 here
     assert np.all(s[1:] < 1e-4 * s[0])
     assert np.abs(np.abs(U[:, 0]) - 1 / np.sqrt(m)).max() < 1e-6 and np.abs(np.abs(V[0]) - 1 / np.sqrt(n)).max() < 1e-6
+
+
+# ---------------------------------------------------------------- K10 / K11 (round 3)
+@pytest.mark.parametrize("n", [1, 2, 31, 32, 33, 62, 64, 65, 124, 250, 500, 513, 1024])
+def test_chol_inv_matches_lapack(K, n):
+    """K10 against np.linalg.cholesky / scipy.linalg.solve_triangular on a Gram-type matrix whose
+    spectrum spans 8 decades (what CholeskyQR factors): L to 1e-13 |L|, L^-1 to cond-scaled rounding
+    (|L Linv - I| <= 1e-10), the triangles above the diagonal exactly zero, status 0 and the
+    min / max of diag(L); and with a diagonal shift."""
+    import scipy.linalg as sla
+
+    rs = np.random.RandomState(n)
+    Q, _ = np.linalg.qr(rs.standard_normal((n, n)))
+    lam = 10.0 ** np.linspace(0, -8, n)
+    A = (Q * lam) @ Q.T
+    A = 0.5 * (A + A.T)
+    for shift in (0.0, 1e-3):
+        L, Linv, info = K.chol_inv(_dev(A), shift=shift)
+        ref = np.linalg.cholesky(A + shift * np.eye(n))
+        st, dmin, dmax = info.cpu().tolist()
+        assert st == 0.0
+        Lh, Xh = L.cpu().numpy(), Linv.cpu().numpy()
+        assert np.array_equal(np.triu(Lh, 1), np.zeros_like(Lh)) and np.array_equal(np.triu(Xh, 1), np.zeros_like(Xh))
+        As = A + shift * np.eye(n)
+        assert np.abs(Lh @ Lh.T - As).max() <= 4e-15 * max(n, 16) * np.abs(As).max()        # backward error
+        assert np.abs(Lh - ref).max() <= 1e-8 * np.abs(ref).max()                            # forward: cond(A) eps
+        assert np.isclose(dmin, np.diag(ref).min(), rtol=1e-9) and np.isclose(dmax, np.diag(ref).max(), rtol=1e-12)
+        Xref = sla.solve_triangular(ref, np.eye(n), lower=True)
+        assert np.abs(Lh @ Xh - np.eye(n)).max() <= 1e-9
+        assert np.abs(Xh - Xref).max() <= 1e-7 * np.abs(Xref).max()
+    L2, none, _ = K.chol_inv(_dev(A), want_inv=False)
+    assert none is None and torch.equal(L2, K.chol_inv(_dev(A))[0])
+
+
+def test_chol_inv_flags_an_indefinite_matrix_without_nans(K):
+    """An indefinite input: status = index + 1 of the first non-positive pivot (as LAPACK's info),
+    every output finite; a NaN input likewise; a strided (non-contiguous) input view."""
+    rs = np.random.RandomState(5)
+    for n in (40, 200):
+        B = rs.standard_normal((n, n))
+        A = B @ B.T + n * np.eye(n)
+        A[n // 2, n // 2] = -1.0
+        L, Linv, info = K.chol_inv(_dev(A))
+        st = int(info[0].item())
+        try:
+            np.linalg.cholesky(A)
+            raise AssertionError("the test matrix must be indefinite")
+        except np.linalg.LinAlgError:
+            pass
+        assert st == n // 2 + 1
+        assert bool(torch.isfinite(L).all()) and bool(torch.isfinite(Linv).all())
+        A[0, 0] = np.nan
+        _, _, info = K.chol_inv(_dev(A))
+        assert int(info[0].item()) == 1
+    big = torch.zeros((64, 80), dtype=torch.float64, device="cuda")
+    A = rs.standard_normal((64, 64))
+    A = A @ A.T + 64 * np.eye(64)
+    big[:, :64] = _dev(A)
+    L, _, info = K.chol_inv(big[:, :64])
+    assert int(info[0].item()) == 0 and np.allclose(L.cpu().numpy(), np.linalg.cholesky(A), rtol=0, atol=1e-11)
+
+
+@pytest.mark.parametrize("n,b1,b2", [(1, 2, 1), (17, 2, 3), (300, 34, 78), (8760, 124, 124), (8760, 500, 500), (8759, 250, 63),
+                                     (1000, 62, 200), (3653, 220, 220)])
+def test_gemm_nt64_matches_fp64_gemm(K, n, b1, b2):
+    """K11 (Y = Q Mt^T, fp64 MFMA) against numpy: dense and lower-triangular Mt, ragged n / b2."""
+    rs = np.random.RandomState(n + b1 + b2)
+    Q = rs.standard_normal((n, b1))
+    Mt = rs.standard_normal((b2, b1))
+    for M in (Mt, np.tril(Mt) if b1 == b2 else Mt[::-1].copy()):
+        Y = K.gemm_nt64(_dev(Q), _dev(M)).cpu().numpy()
+        ref = Q @ M.T
+        assert Y.shape == (n, b2)
+        assert np.abs(Y - ref).max() <= 1e-13 * (np.abs(Q) @ np.abs(M).T).max()
+    # odd inner dimension: the library path
+    Y = K.gemm_nt64(_dev(Q[:, :b1 - 1] if b1 > 2 else Q), _dev(Mt[:, :b1 - 1] if b1 > 2 else Mt))
+    assert Y.shape == (n, b2)

@@ -73,6 +73,10 @@ def _worker(rank, world, port, path, cfg, q, stream_bytes=0):
     ("standard", 2, True, True, [850, 1000], 2),
     ("randomized", 1, True, False, None, 2),
     ("standard", 3, False, False, [500], 3),          # un-centred temperature: the mean-deflation path
+    # round 3, the driver's node size: 8 ranks, 36 latitude rows -> bands of 4 and 5 rows (uneven), the
+    # packed-triangle Gram all-reduce, the stats all-gather, the broadcasts and the chunked gather to the root
+    ("standard", 2, True, False, [850], 8),
+    ("randomized", 1, True, False, [1000, 500], 8),
 ])
 def test_latitude_band_shards_assemble_to_the_single_rank_result(tmp_path, svd_type, d, center, scale, levels, world):
     from dmd_era5_amd import hdf5_lite, io_netcdf
@@ -116,6 +120,14 @@ def test_latitude_band_shards_assemble_to_the_single_rank_result(tmp_path, svd_t
     U1, s1, V1, coords1, X1, Xm1, Xs1 = _run(path, cfg, dsvd.Comm())
     nlev = len(levels) if levels else 3
     assert U.shape == U1.shape == (d * 2 * nlev * 36 * 72, 3)
+    if world == 8:
+        from dmd_era5_amd.era5_svd import lat_band
+
+        bands = [lat_band(36, r, 8) for r in range(8)]
+        assert sorted({b[1] - b[0] for b in bands}) == [4, 5] and bands[0][0] == 0 and bands[-1][1] == 36
+        real = [lat_band(721, r, 8) for r in range(8)]                     # the 0.25-degree grid: 721 rows over 8 GPUs
+        assert [b[1] - b[0] for b in real].count(90) == 7 and sum(b[1] - b[0] for b in real) == 721
+        assert all(real[r][1] == real[r + 1][0] for r in range(7))
     assert np.array_equal(X, X1.values)                                   # same rows in the same order
     assert np.array_equal(delay, np.asarray(coords1["delay"].values))
     if center and d > 1:

@@ -13,7 +13,10 @@ void dmdx_set_error(const char* fmt, ...);
 
 // measurement aid (dmdx_set_clock_probe): 3 device uint64 the stamped kernels (K1 / K3 batch
 // launches, K2) add their core-clock cycles, reference ticks and workgroup count to; null = off
-extern unsigned long long* dmdx_clock_probe_ptr;
+extern thread_local unsigned long long* dmdx_clock_probe_ptr;   // (per thread: main() primes the libraries on a side thread)
+
+// compute units of the current device (cached per device; <= 0 if the query fails)
+int dmdx_device_cus();
 
 #define DMDX_CHECK_ARG(cond, ...)        \
   do {                                   \

@@ -44,7 +44,7 @@ __global__ __launch_bounds__(ETH) void eigh_jacobi_kernel(const double* __restri
   }
   __syncthreads();
 
-  int sweep = 0;
+  int sweep = 0, converged = 0;   // sweeps_out: sweeps used (the rotation-free one included), MAX_SWEEPS + 1 = no convergence
   for (; sweep < MAX_SWEEPS; ++sweep) {
     int nrot = 0;
     for (int step = 0; step < ne - 1; ++step) {
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(ETH) void eigh_jacobi_kernel(const double* __restri
       }
       __syncthreads();
     }
-    if (nrot == 0) break;
+    if (nrot == 0) { converged = 1; ++sweep; break; }
   }
 
   // ---- eigenvalues descending (rank sort; ties broken by index), eigenvectors in columns
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(ETH) void eigh_jacobi_kernel(const double* __restri
     const int i = idx / n, j = idx - i * n;
     Vout[(int64_t)i * ldv + j] = Vs[i * ELD + order[j]];
   }
-  if (tid == 0 && sweeps_out) *sweeps_out = sweep;
+  if (tid == 0 && sweeps_out) *sweeps_out = converged ? sweep : MAX_SWEEPS + 1;
 }
 
 }  // namespace

@@ -48,7 +48,18 @@
 
 #include "dmdx_common.h"
 
-unsigned long long* dmdx_clock_probe_ptr = nullptr;  // dmdx_set_clock_probe (measurement aid)
+thread_local unsigned long long* dmdx_clock_probe_ptr = nullptr;  // dmdx_set_clock_probe (measurement aid)
+
+int dmdx_device_cus() {
+  static int cached[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -1;
+  if (cached[dev] == 0) {
+    int v = 0;
+    cached[dev] = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : -1;
+  }
+  return cached[dev];
+}
 
 namespace {
 

@@ -133,7 +133,7 @@ __global__ __launch_bounds__(JTH) void jacobi_svd_kernel(JacobiParams p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = p.n, nblk = p.nblk, nwg = gridDim.x, wg = blockIdx.x;
   unsigned epoch = 0;
-  bool alive = true;
+  bool alive = true, converged = false;
   int sweep = 0;
 
   for (; sweep < JMAX_SWEEPS && alive; ++sweep) {
@@ -211,6 +211,7 @@ __global__ __launch_bounds__(JTH) void jacobi_svd_kernel(JacobiParams p) {
     const int any = flag;
     __syncthreads();
     if (any == 0) {
+      converged = true;
       ++sweep;
       break;
     }
@@ -234,7 +235,8 @@ __global__ __launch_bounds__(JTH) void jacobi_svd_kernel(JacobiParams p) {
     ++epoch;
     alive = grid_barrier(p.bar, epoch * (unsigned)nwg);
   }
-  if (wg == 0 && tid == 0 && p.sweeps_out) *p.sweeps_out = alive ? sweep : -1;
+  // sweeps used (the rotation-free one included); JMAX_SWEEPS + 1 = the limit was hit without one; -1 = barrier timeout
+  if (wg == 0 && tid == 0 && p.sweeps_out) *p.sweeps_out = alive ? (converged ? sweep : JMAX_SWEEPS + 1) : -1;
   if (!alive) return;
 
   // ---- rank (descending, ties by index) and normalised output
@@ -262,7 +264,10 @@ __global__ __launch_bounds__(JTH) void jacobi_svd_kernel(JacobiParams p) {
 
 }  // namespace
 
-extern "C" int dmdx_svd_jacobi_max_n(void) { return JMAXN; }
+extern "C" int dmdx_svd_jacobi_max_n(void) {
+  const int cus = dmdx_device_cus();   // n / 16 workgroups must be co-resident, one per CU
+  return (cus > 0 && 16 * cus < JMAXN) ? 16 * cus : JMAXN;
+}
 
 extern "C" size_t dmdx_svd_jacobi_workspace_bytes(int64_t n) {
   return 256 + (size_t)(n > 0 ? n : 0) * sizeof(double);
@@ -280,6 +285,18 @@ extern "C" int dmdx_svd_jacobi_f64(double* C, int64_t n, int64_t ldc, double* si
     return DMDX_E_WORKSPACE;
   }
   hipStream_t st = (hipStream_t)stream;
+  // the workgroups meet at a spin barrier: all of them must be resident at once (one per CU: up to
+  // 128 KB of LDS each).  On a partitioned device (CPX: 32 CUs) a larger grid would spin to its
+  // limit before reporting -1: refuse it here, the callers fall back to the library at once.
+  {
+    int nb2 = (int)((n + JW - 1) / JW);
+    nb2 += nb2 & 1;
+    const int cus = dmdx_device_cus();
+    if (cus > 0 && nb2 / 2 > cus) {
+      dmdx_set_error("svd_jacobi: n = %lld needs %d co-resident workgroups, the device has %d CUs", (long long)n, nb2 / 2, cus);
+      return DMDX_E_UNSUPPORTED;
+    }
+  }
   DMDX_HIP(hipMemsetAsync(workspace, 0, 256, st));
   JacobiParams p{};
   p.C = C;

@@ -52,7 +52,7 @@ FP64_MAX_BYTES = 2 << 30
 
 
 def _svd_fp64(X: np.ndarray, svd_type: str, n_components: int, device, random_state=None, omega=None,
-              n_oversamples: int = 10, n_iter="auto", **_ignored):
+              n_oversamples: int = 10, n_iter="auto", power_iteration_normalizer: str = "auto", **_ignored):
     """The same two algorithms in fp64, for float64 input small enough to hold twice: the Gram
     X^T X on the fp64 MFMA path (K9), the eigen stage of the fp32 engine (already fp64), the
     projections through the library's fp64 GEMM.  Singular values agree with LAPACK's to
@@ -95,9 +95,27 @@ def _svd_fp64(X: np.ndarray, svd_type: str, n_components: int, device, random_st
             rs = random_state if isinstance(random_state, np.random.RandomState) else np.random.RandomState(random_state)
             omega = rs.normal(size=(cols, n_components + n_oversamples))[:, :l]
         Q = torch.as_tensor(np.asarray(omega, dtype=np.float64)).to(dev)
-        for _ in range(n_it):                                    # extmath.py:349-351, QR normaliser
-            Q, _ = torch.linalg.qr(A @ Q)
-            Q, _ = torch.linalg.qr(A.T @ Q)
+        # the normaliser sklearn would take (extmath.py:314-326, 342-353): 'auto' = none for n_iter <= 2,
+        # LU above; in fp64 its arithmetic is followed literally (the fp32 engine re-orthonormalises
+        # where sklearn's 'auto' would not, because un-normalised fp32 iterates lose the trailing
+        # directions; in fp64 they do not)
+        norm = power_iteration_normalizer
+        if norm == "auto":
+            norm = "none" if n_it <= 2 else "LU"
+        if norm not in ("none", "LU", "QR"):
+            raise ValueError(f"power_iteration_normalizer must be 'auto', 'none', 'LU' or 'QR', got {norm!r}")
+
+        def normalise(M):
+            if norm == "QR":
+                return torch.linalg.qr(M)[0]
+            if norm == "LU":
+                P, L, _ = torch.linalg.lu(M)                     # scipy.linalg.lu(..., permute_l=True)[0] = P L
+                return P @ L
+            return M
+
+        for _ in range(n_it):                                    # extmath.py:349-351
+            Q = normalise(A @ Q)
+            Q = normalise(A.T @ Q)
         Q, _ = torch.linalg.qr(A @ Q)                            # extmath.py:355
         Uh, s, Vh = torch.linalg.svd(Q.T @ A, full_matrices=False)
         U, s, Vh = (Q @ Uh)[:, :k], s[:k], Vh[:k]

@@ -495,8 +495,10 @@ def _device_pipeline(ds: Dataset, parsed_config: dict, comm=None, kern=None, dev
         # the code objects of every kernel are loaded when the real matrix is resident.  Only for
         # slices of >= 1 GiB: the reference's default config (0.4 GB, scripts/bench_default_config.py)
         # ingests in 0.1-0.4 s, less than the toy run takes -- 2.62 s primed against 1.99 s.
+        # (DMDX_PRIME_MIN_BYTES: tests force the primer onto small slices)
+        prime_min = int(os.environ.get("DMDX_PRIME_MIN_BYTES", str(1 << 30)))
         primer = _prime_async(device, parsed_config["svd_type"]) if device.type == "cuda" and \
-            4 * rows * len(take) >= (1 << 30) else None
+            4 * rows * len(take) >= prime_min else None
         stats, total = {"mean": [], "std": []}, 0
         for name in names:
             vb, _, nbytes = _upload_variable(ds[name], level_idx, take, device, kern, center, scale, stats, band)
@@ -648,14 +650,20 @@ def _prime_async(device, svd_type: str):
 
             torch.cuda.set_device(device)
             k2 = HipKernels()
-            g = torch.Generator(device=device)
-            g.manual_seed(0)
-            toy = torch.randn((1024, 8192), device=device, dtype=torch.float32, generator=g)
-            halves = [toy[:, :4096].contiguous(), toy[:, 4096:].contiguous()]
-            if svd_type == "standard":
-                dsvd.svd_snapshots(halves, 12, delay=2, kern=k2)
-            else:
-                dsvd.svd_randomized(halves, 12, delay=2, random_state=0, kern=k2)
+            # a stream of its own: the toy run (it includes the grid-barrier kernels K7L / K10) must not
+            # queue in front of, or between, the ingest's copies and K5 launches on the default stream;
+            # its workspaces (a few MB) belong to this provider and stream and are released below
+            side = torch.cuda.Stream(device=device)
+            with torch.cuda.stream(side):
+                g = torch.Generator(device=device)
+                g.manual_seed(0)
+                toy = torch.randn((1024, 8192), device=device, dtype=torch.float32, generator=g)
+                halves = [toy[:, :4096].contiguous(), toy[:, 4096:].contiguous()]
+                if svd_type == "standard":
+                    dsvd.svd_snapshots(halves, 12, delay=2, kern=k2)
+                else:
+                    dsvd.svd_randomized(halves, 12, delay=2, random_state=0, kern=k2)
+                side.synchronize()
             k2.release_workspace()
         except Exception as e:      # priming is an optimisation: never fail the run for it
             logger.debug(f"library priming failed: {e}")

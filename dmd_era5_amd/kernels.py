@@ -319,7 +319,7 @@ class HipKernels:
         # the kernel stops silently at its sweep limit (30): eigenpairs of a run that did not
         # converge must not be used as exact by the Rayleigh-Ritz steps
         self.last_eigh_sweeps = int(info.item())
-        if self.last_eigh_sweeps >= 30:
+        if self.last_eigh_sweeps > 30:      # (31 = no rotation-free sweep within the limit of 30)
             raise _lib.DmdxError(f"eigh_small: no convergence in {self.last_eigh_sweeps} Jacobi sweeps (n = {n})")
         return w, V
 
@@ -350,7 +350,7 @@ class HipKernels:
         if sweeps < 0:
             raise _lib.DmdxError("svd_jacobi: the workgroups of the launch could not synchronise "
                                  "(the device is occupied by another kernel that does not end)")
-        if sweeps >= 40:
+        if sweeps > 40:                     # (41 = no rotation-free sweep within the limit of 40)
             raise _lib.DmdxError(f"svd_jacobi: no convergence in {sweeps} sweeps (n = {n})")
         self.last_jacobi_sweeps = sweeps
         return sigma, Zt

@@ -495,6 +495,18 @@ def top_eigh(G: torch.Tensor, l: int, method: str = "auto", tol: float = 1e-9,
     if method != "cheb":
         raise ValueError(f"top_eigh: unknown method {method!r}")
 
+    if n % 2 == 1 and n > 1024 and getattr(kern, "symm_skinny", None) is not None:
+        # K8 (fp64 MFMA products G Q) needs an even order and leading dimension; an odd Gram -- delay
+        # embedding d = 2 of an even number of snapshots, the reference's default config: n = 8759 --
+        # would send every product of the stage to the library GEMM (1.0 instead of 0.33 ms each).
+        # One zero row and column are appended (0.3 ms for 614 MB): the extra eigenvalue is 0, the
+        # wanted pairs are unchanged and have a zero last component.
+        Gp = torch.zeros((n + 1, n + 1), dtype=G.dtype, device=G.device)
+        Gp[:n, :n] = G
+        lam, Vp = top_eigh(Gp, l, method="cheb", tol=tol, max_outer=max_outer, info=info, kern=kern)
+        if info is not None:
+            info["eig_padded_to_even"] = True
+        return lam, Vp[:n].contiguous()
     b = min(n // 3, l + max(8, l // 4) + 1) & ~1    # even widths: K8's 16-byte fragment loads
     gen = torch.Generator(device=G.device).manual_seed(1234)  # (a host draw + upload costs 7 ms)
     Q = torch.randn((n, b), dtype=torch.float64, generator=gen, device=G.device)

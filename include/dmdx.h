@@ -140,7 +140,8 @@ int dmdx_scale_columns_f32(float* Y, int64_t m, int64_t l, int64_t ldy,
 /* ---- K7: eigenpairs of a small symmetric fp64 matrix, one launch -------------
  * A (n x n, lda, either storage order: only (A + A^T)/2 is used), n <= dmdx_eigh_small_max_n()
  * (96).  w[0..n) eigenvalues in DESCENDING order, V (n x n, row-major, ldv): column j is the
- * unit eigenvector of w[j].  sweeps: nullable device int, number of Jacobi sweeps used.
+ * unit eigenvector of w[j].  sweeps: nullable device int, number of Jacobi sweeps used (the
+ * rotation-free last one included); limit + 1 (31) = no rotation-free sweep within the limit.
  * Replaces the LAPACK syevd calls on the projected matrices of the method of snapshots (the
  * part of np.linalg.svd, era5_svd.py:251, that is left once X is reduced to its Gram matrix). */
 int dmdx_eigh_small_max_n(void);
@@ -152,8 +153,10 @@ int dmdx_eigh_small_f64(const double* A, int64_t n, int64_t lda, double* w, doub
  * must be able to run them all at once, i.e. nothing else may occupy the device for good).
  * C: n x n, COLUMN c at C + c * ldc (contiguous), overwritten.  sigma[0..n): singular values in
  * DESCENDING order; Zt (n x n, ldz): ROW j = unit left singular vector of sigma[j] (zero rows for
- * zero singular values).  sweeps (nullable device int): sweeps used, -1 if the workgroups could
- * not synchronise (results invalid).  With C = chol(T) (or S L for T = S L L^T S) this gives
+ * zero singular values).  sweeps (nullable device int): sweeps used (the rotation-free last one
+ * included), 41 = the limit of 40 was hit without one, -1 if the workgroups could not synchronise
+ * (results invalid); a grid larger than the device's CU count is refused (DMDX_E_UNSUPPORTED;
+ * dmdx_svd_jacobi_max_n() already accounts for it).  With C = chol(T) (or S L for T = S L L^T S) this gives
  * the eigenpairs of the positive definite T = C C^T with errors relative to each eigenvalue:
  * the (b x b) Rayleigh-Ritz matrices and the graded refinement matrix of the method of
  * snapshots beyond K7's n <= 96 -- the LAPACK syevd / gesvd calls left of np.linalg.svd

@@ -1030,3 +1030,21 @@ def test_gemm_nt64_matches_fp64_gemm(K, n, b1, b2):
     # odd inner dimension: the library path
     Y = K.gemm_nt64(_dev(Q[:, :b1 - 1] if b1 > 2 else Q), _dev(Mt[:, :b1 - 1] if b1 > 2 else Mt))
     assert Y.shape == (n, b2)
+
+
+@pytest.mark.parametrize("n_iter,norm", [("auto", "auto"), (2, "auto"), (4, "QR"), (3, "none")])
+def test_fp64_randomized_branch_follows_sklearns_normaliser(n_iter, norm):
+    """float64 input (the reference's mock slices) takes the fp64 engine path; its randomized branch
+    follows sklearn's power_iteration_normalizer choices literally (it hard-coded QR):
+    against sklearn.utils.extmath.randomized_svd itself with the same random_state, to fp64 rounding
+    amplified by the conditioning of the iterates."""
+    from sklearn.utils.extmath import randomized_svd
+
+    from dmd_era5_amd.engine import svd_numpy
+
+    X = orc.lowrank_matrix(3000, 120, 40, seed=11).astype(np.float64)
+    k = 6
+    Ur, sr, Vr = randomized_svd(X, k, n_iter=n_iter, power_iteration_normalizer=norm, random_state=0)
+    U, s, V = svd_numpy(X, "randomized", k, device="cuda", random_state=0, n_iter=n_iter, power_iteration_normalizer=norm)
+    assert U.dtype == np.float64 and np.allclose(s, sr, rtol=1e-9)
+    assert np.all(np.abs(np.sum(U * Ur, axis=0)) > 1 - 1e-8) and np.all(np.abs(np.sum(V * Vr, axis=1)) > 1 - 1e-8)

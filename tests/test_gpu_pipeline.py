@@ -220,7 +220,7 @@ def test_create_mock_era5_svd_and_combine_like_the_reference_tests():
     assert dx["U"].shape[0] == dx["X"].shape[0] and dx["V"].shape[1] == dx["X"].shape[1]
 
 
-@pytest.mark.parametrize("ranks", ["two-over-gloo", "one-over-rccl", "five-over-gloo"])
+@pytest.mark.parametrize("ranks", ["two-over-gloo", "one-over-rccl", "four-over-gloo"])
 @pytest.mark.parametrize("streamed", [False, True])
 def test_main_sharded_over_two_ranks(svd_base_config, tmp_path, monkeypatch, streamed, ranks):
     """``main`` under torch.distributed.run, one process per rank, the space
@@ -242,8 +242,9 @@ def test_main_sharded_over_two_ranks(svd_base_config, tmp_path, monkeypatch, str
     from dmd_era5_amd import io_netcdf
     from dmd_era5_amd.era5_svd import main
 
-    if ranks == "five-over-gloo" and streamed:
-        pytest.skip("the five-rank rehearsal (uneven bands 7,7,7,7,8; at most 6 processes may share the box's GPU) runs the resident path")
+    if ranks == "four-over-gloo" and streamed:
+        pytest.skip("the four-rank rehearsal (at most 6 processes may share the box's GPU, this one included) runs the resident path; "
+                    "8 ranks with uneven bands: tests/test_sharded_pipeline.py (CPU, gloo)")
     here = os.path.dirname(os.path.abspath(__file__))
     cfg = dict(svd_base_config, start_datetime="2019-01-01T00", end_datetime="2019-01-03T00",
                variables="temperature,v_component_of_wind", levels="850,1000", svd_type="standard",
@@ -281,7 +282,7 @@ def test_main_sharded_over_two_ranks(svd_base_config, tmp_path, monkeypatch, str
         env.update(DMDX_COMM_FORCE="1", DMDX_TEST_EXPECT_BACKEND="nccl")
     if streamed:
         env["DMDX_STREAM_BYTES"] = str(4 * 4 * 49 * 2 * 72)
-    nproc = {"two-over-gloo": "2", "one-over-rccl": "1", "five-over-gloo": "5"}[ranks]
+    nproc = {"two-over-gloo": "2", "one-over-rccl": "1", "four-over-gloo": "4"}[ranks]
     run = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", nproc,
                           "--master-addr", "127.0.0.1", "--master-port", str(port),
                           os.path.join(here, "dist_main_worker.py")],
@@ -289,8 +290,8 @@ def test_main_sharded_over_two_ranks(svd_base_config, tmp_path, monkeypatch, str
     assert run.returncode == 0, run.stdout[-3000:] + run.stderr[-3000:]
     if ranks == "two-over-gloo":
         assert "latitude rows 0:18" in run.stdout and "latitude rows 18:36" in run.stdout
-    elif ranks == "five-over-gloo":
-        assert "latitude rows 0:7" in run.stdout and "latitude rows 28:36" in run.stdout
+    elif ranks == "four-over-gloo":
+        assert "latitude rows 0:9" in run.stdout and "latitude rows 27:36" in run.stdout
     else:
         assert "backend nccl" in run.stdout and "collectives issued" in run.stdout
     two = io_netcdf.open_dataset(p["save_path"])
@@ -527,3 +528,36 @@ def test_float64_mock_slice_comes_back_with_float64_accuracy(svd_base_config, pr
 
     U2, s2, V2 = svd_on_era5(DataArray(X, ("space", "time")), p)
     assert U2.dtype == np.float64 and np.abs(s2 / so - 1).max() < (1e-11 if svd_type == "standard" else 1e-9)
+
+
+@pytest.mark.parametrize("svd_type", ["standard", "randomized"])
+def test_main_with_the_library_primer_on_a_side_thread(svd_base_config, project_root, monkeypatch, svd_type):
+    """main() primes the libraries on a side thread (a toy SVD with a kernel provider and a stream
+    of its own, incl. the grid-barrier kernels) while the slice is ingested -- only for slices of
+    >= 1 GiB by default; DMDX_PRIME_MIN_BYTES=0 forces it here.  The decomposition must be the one
+    a run without the primer returns (no test ran with priming on)."""
+    from dmd_era5_amd import era5_svd
+    from dmd_era5_amd.era5_svd import main
+
+    cfg = dict(svd_base_config, start_datetime="2019-01-01T00", end_datetime="2019-01-04T00",
+               variables="temperature,u_component_of_wind", levels="1000,850", svd_type=svd_type,
+               mean_center=True, scale=False, delay_embedding=2, n_components=5, svd_seed=0)
+    _write_slice(cfg, seed=21, dtype=np.float32)
+    monkeypatch.setenv("DMDX_NO_PRIME", "1")
+    off, _, _ = main(cfg)
+    monkeypatch.delenv("DMDX_NO_PRIME")
+    monkeypatch.setenv("DMDX_PRIME_MIN_BYTES", "0")
+    era5_svd._PRIMED.clear()
+    started = []
+    real = era5_svd._prime_async
+
+    def spy(device, typ):
+        t = real(device, typ)
+        started.append(t)
+        return t
+
+    monkeypatch.setattr(era5_svd, "_prime_async", spy)
+    on, _, _ = main(cfg)
+    assert started and started[0] is not None and not started[0].is_alive()
+    for name in ("U", "s", "V"):
+        assert np.array_equal(on[name].values, off[name].values), name

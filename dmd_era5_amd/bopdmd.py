@@ -167,6 +167,132 @@ def _project(alpha, t, H, rank_tol=None, use_qr: bool = True):
     return Phi, U, Ginv, B, R
 
 
+class _GramEval:
+    """One evaluation of the variable projection at alpha on the GPU, from ONE pass over the tall
+    matrices (round 3; replaces CholeskyQR2 of Phi through rocSOLVER / rocBLAS trsm + six tall complex
+    GEMMs per Levenberg-Marquardt iteration, ~35 library launches of 8-18 ms in all):
+
+    * Phi = exp(t alpha^T) and W = diag(t) Phi: one launch of ``dmdx_exp_basis`` (complex128);
+    * the complex Gram block  [Phi W]^H [Phi W H]  as the REAL product of the interleaved
+      (re, im) views -- a complex n x c matrix is a real n x 2c matrix in memory -- on the fp64 MFMA
+      kernel K9 (``gemm_tn64``: one launch + its reduce); the four real blocks (rr, ri, ir, ii) of
+      every complex entry are recombined on the small result:  A^H B = (rr + ii) + i (ri - ir);
+    * G = Phi^H Phi = L L^H through K10 on the real embedding [[Gr, -Gi], [Gi, Gr]] (symmetric
+      positive definite, order 2r <= 1024): one launch gives the factor's inverse, hence
+      G^-1 and B = G^-1 Phi^H H;  the Levenberg-Marquardt system (J^H J + lambda D) delta = g is
+      Hermitian positive definite and solved the same way (was an LU through rocSOLVER);
+    * the residual R = H - Phi B explicitly (its norm decides acceptance and convergence: formed
+      from Gram pieces it would lose everything below 1e-8 ||H||), as the real product
+      [Phi_r Phi_i] M on K11;  C = W^H R, P W and the Gauss-Newton pieces from the Gram blocks:
+      (P W)^H (P W) = W^H W - (W^H Phi) G^-1 (Phi^H W),   C = W^H H - (W^H Phi) B.
+
+    Everything is complex128 whatever H's dtype (complex64 input is cast once: the n x r basis is
+    28 MB).  A basis too ill-conditioned for the normal equations (K10 reports a failed
+    factorisation or a diagonal spread beyond 1 / sqrt(rank_tol)) makes ``evaluate`` return False:
+    the caller switches to the library route (economy SVD with truncation) for good."""
+
+    def __init__(self, H: torch.Tensor, t: torch.Tensor, kern):
+        self.kern = kern
+        self.H = H.to(torch.complex128).contiguous()
+        self.t = t
+        n, ns = self.H.shape
+        self.n, self.ns = n, ns
+        self.normH2 = float((self.H.real ** 2 + self.H.imag ** 2).sum())
+        self.buf = None
+
+    @staticmethod
+    def _cplx(Cm: torch.Tensor, a: int, b: int) -> torch.Tensor:
+        """Real product of interleaved views (2a x 2b) -> complex A^H B (a x b)."""
+        v = Cm.view(a, 2, b, 2)
+        return torch.complex(v[:, 0, :, 0] + v[:, 1, :, 1], v[:, 0, :, 1] - v[:, 1, :, 0])
+
+    @staticmethod
+    def _embed(G: torch.Tensor) -> torch.Tensor:
+        """Hermitian G (r x r complex) -> the real symmetric [[Gr, -Gi], [Gi, Gr]] (2r x 2r)."""
+        Gr, Gi = G.real, G.imag
+        return torch.cat([torch.cat([Gr, -Gi], dim=1), torch.cat([Gi, Gr], dim=1)], dim=0).contiguous()
+
+    def _solve_hpd(self, G: torch.Tensor, Y: torch.Tensor, rank_tol: float | None):
+        """G^-1 Y and G^-1 for Hermitian positive definite G: K10 on the real embedding."""
+        r = G.shape[0]
+        if 2 * r > getattr(self.kern, "chol_max_n", 0):
+            return None
+        L, Linv, info = self.kern.chol_inv(self._embed(G))
+        st, dmin, dmax = info.tolist()
+        if st != 0.0 or not (math.isfinite(dmin) and math.isfinite(dmax)) or dmin <= 0.0:
+            return None
+        if rank_tol is not None and dmin < math.sqrt(rank_tol) * dmax:
+            return None
+        Ginv_e = Linv.T @ Linv                                   # (2r, 2r) = embedding of G^-1
+        Ginv = torch.complex(Ginv_e[:r, :r], Ginv_e[r:, :r])
+        return Ginv @ Y, Ginv
+
+    def evaluate(self, alpha: torch.Tensor, rank_tol: float = 1e-12):
+        """-> dict of the pieces at alpha, None when exp(alpha t) is not finite, False when the basis
+        is too ill-conditioned for this route."""
+        kern, n, ns = self.kern, self.n, self.ns
+        r = alpha.numel()
+        Phi, W = kern.exp_basis(alpha, self.t, torch.complex128, want_w=True)
+        if self.buf is None or self.buf.shape[1] != 2 * r + ns:
+            self.buf = torch.empty((n, 2 * r + ns), dtype=torch.complex128, device=self.H.device)
+            self.buf[:, 2 * r:] = self.H
+        self.buf[:, :r] = Phi
+        self.buf[:, r:2 * r] = W
+        F = torch.view_as_real(self.buf).reshape(n, 2 * (2 * r + ns))     # interleaved (re, im) columns
+        Cm = kern.gemm_tn64(F[:, :4 * r], F)                               # (4r, 4r + 2 ns) real
+        S = self._cplx(Cm, 2 * r, 2 * r + ns)                              # [Phi W]^H [Phi W H]
+        if not bool(torch.isfinite(torch.diagonal(S[:r, :r]).real).all()):
+            return None
+        PhP, PhW, PhH = S[:r, :r], S[:r, r:2 * r], S[:r, 2 * r:]
+        WhW, WhH = S[r:, r:2 * r], S[r:, 2 * r:]
+        PhP = 0.5 * (PhP + PhP.conj().T)
+        sol = self._solve_hpd(PhP, torch.cat([PhH, PhW], dim=1), rank_tol)
+        if sol is None:
+            return False
+        X, Ginv = sol
+        B, GiPhW = X[:, :ns], X[:, ns:]                                   # B = G^-1 Phi^H H ; G^-1 Phi^H W
+        # R = H - Phi B as a real product on K11: [Phi_r | Phi_i interleaved] (n x 2r) times the real
+        # (2r x 2 ns) image of B, given transposed
+        Bt = torch.view_as_real(B.T.contiguous())                          # (ns, r, 2): [j][c] -> (Br, Bi)
+        Mt = torch.stack([torch.stack([Bt[..., 0], -Bt[..., 1]], dim=-1).reshape(ns, 2 * r),
+                          torch.stack([Bt[..., 1], Bt[..., 0]], dim=-1).reshape(ns, 2 * r)], dim=1).reshape(2 * ns, 2 * r)
+        PB = kern.gemm_nt64(F[:, :2 * r], Mt.contiguous())                 # (n, 2 ns) = interleaved Phi B
+        R = self.H - torch.view_as_complex(PB.view(n, ns, 2))
+        res2 = float((R.real ** 2 + R.imag ** 2).sum())
+        return {"Phi": Phi, "B": B, "R": R, "err": math.sqrt(max(res2, 0.0) / max(self.normH2, 1e-300)), "Ginv": Ginv,
+                "WhH": WhH, "WhW": WhW, "PhW": PhW, "GiPhW": GiPhW}
+
+    def normal_matrix(self, pc: dict):
+        """(J^H J, g) of the variable-projection functional from the pieces of ``evaluate``."""
+        B, Ginv = pc["B"], pc["Ginv"]
+        WhP = pc["PhW"].conj().T
+        PWhPW = pc["WhW"] - WhP @ pc["GiPhW"]                              # (P W)^H (P W), P = I - Phi G^-1 Phi^H
+        PWhPW = 0.5 * (PWhPW + PWhPW.conj().T)
+        C = pc["WhH"] - WhP @ B                                            # W^H R
+        JtJ = PWhPW * (B.conj() @ B.T) + Ginv * (C.conj() @ C.T)
+        g = (C * B.conj()).sum(dim=1)
+        return 0.5 * (JtJ + JtJ.conj().T), g
+
+    def lm_step(self, JtJ: torch.Tensor, g: torch.Tensor, dg: torch.Tensor, lmb: float):
+        sol = self._solve_hpd(JtJ + lmb * torch.diag(dg), g[:, None], None)
+        if sol is None:
+            return torch.linalg.solve(JtJ + lmb * torch.diag(dg), g)
+        return sol[0][:, 0]
+
+
+def _gram_route(H: torch.Tensor):
+    """The HIP kernel provider when H lives on a GPU with libdmdx (else None: library route)."""
+    if not H.is_cuda:
+        return None
+    try:
+        from .kernels import default_kernels
+
+        kern = default_kernels()
+    except Exception:
+        return None
+    return kern if all(hasattr(kern, f) for f in ("gemm_tn64", "chol_inv", "gemm_nt64", "exp_basis")) else None
+
+
 def optdmd(H: torch.Tensor, t: torch.Tensor, r: int, alpha0: torch.Tensor | None = None,
            maxiter: int = 30, tol: float = 1e-6, eps_stall: float | None = None, init_lambda: float = 1.0,
            lamup: float = 2.0, maxlam: int = 52) -> OptDMDResult:
@@ -191,63 +317,92 @@ def optdmd(H: torch.Tensor, t: torch.Tensor, r: int, alpha0: torch.Tensor | None
     normH = torch.linalg.norm(H)
     lam = float(init_lambda)
 
-    pieces = _project(alpha, t, H)
-    if pieces is None:
+    # Two routes to the same pieces (B, the residual norm, J^H J and g): the Gram route on our own
+    # kernels (_GramEval: GPU, complex128 inside) and the library route (_project: CholeskyQR2 / SVD
+    # of Phi through torch -- the CPU path, and the fallback for ill-conditioned bases).
+    kern = _gram_route(H)
+    ge = _GramEval(H, t, kern) if kern is not None else None
+    route = {"gram": ge is not None}
+
+    def evaluate(a):
+        """-> (err, B, normal) with normal() -> (JtJ, g) in complex128, or None (not finite)."""
+        if route["gram"]:
+            pc = ge.evaluate(a)
+            if pc is None:
+                return None
+            if pc is not False:
+                return pc["err"], pc["B"], (lambda pc=pc: ge.normal_matrix(pc))
+            route["gram"] = False                                   # ill-conditioned basis: library route from here on
+        pieces = _project(a, t, H)
+        if pieces is None or not bool(torch.isfinite(pieces[4].real).all()):
+            return None
+        Phi, U, Ginv, B, R = pieces
+
+        def normal():
+            W = tw[:, None] * Phi
+            PW = W - U @ (U.conj().T @ W)
+            C = W.conj().T @ R                                           # (r, n_s)
+            A1 = (PW.conj().T @ PW) * (B.conj() @ B.T)
+            A2 = Ginv * (C.conj() @ C.T)                                  # (Phi^H Phi)^-1 = V S^-2 V^H
+            return (A1 + A2).to(torch.complex128), (C * B.conj()).sum(dim=1).to(torch.complex128)
+
+        return float(torch.linalg.norm(R) / normH), B, normal
+
+    state = evaluate(alpha)
+    if state is None:
         raise ValueError("optdmd: exp(alpha0 * t) is not finite in the working dtype")
-    Phi, U, Ginv, B, R = pieces
-    err = float(torch.linalg.norm(R) / normH)
+    err, B, normal = state
     n_iter, converged = 0, err < tol
     errs = [err]
     n_proj = 1
     while n_iter < maxiter and not converged:
         n_iter += 1
-        W = tw[:, None] * Phi
-        PW = W - U @ (U.conj().T @ W)
-        C = W.conj().T @ R                                           # (r, n_s)
-        A1 = (PW.conj().T @ PW) * (B.conj() @ B.T)
-        A2 = Ginv * (C.conj() @ C.T)                                  # (Phi^H Phi)^-1 = V S^-2 V^H
-        JtJ = (A1 + A2).to(torch.complex128)
-        g = (C * B.conj()).sum(dim=1).to(torch.complex128)
+        JtJ, g = normal()
         dg = torch.diagonal(JtJ).real.clamp_min(1e-300).to(torch.complex128)
 
         def trial(lmb):
-            M = JtJ + lmb * torch.diag(dg)
-            delta = torch.linalg.solve(M, g)
+            if route["gram"]:
+                delta = ge.lm_step(JtJ, g, dg, lmb)
+            else:
+                delta = torch.linalg.solve(JtJ + lmb * torch.diag(dg), g)
             a_new = alpha + delta
-            pieces = _project(a_new, t, H)
+            st = evaluate(a_new)
             nonlocal n_proj
             n_proj += 1
-            if pieces is None or not bool(torch.isfinite(pieces[4].real).all()):
+            if st is None:
                 return a_new, None, math.inf
-            return a_new, pieces, float(torch.linalg.norm(pieces[4]) / normH)
+            return a_new, st, st[0]
 
-        a_new, pieces, e_new = trial(lam)
+        a_new, st, e_new = trial(lam)
         if e_new < err:
             lam = max(lam / lamup, 1e-12)
         else:
             improved = False
             for _ in range(maxlam):
                 lam *= lamup
-                a_new, pieces, e_new = trial(lam)
+                a_new, st, e_new = trial(lam)
                 if e_new < err:
                     improved = True
                     break
             if not improved:
                 break                                               # stalled: keep the current alpha
         gain = err - e_new
-        alpha, (Phi, U, Ginv, B, R), err = a_new, pieces, e_new
+        alpha, err = a_new, e_new
+        _, B, normal = st
         errs.append(err)
         if err < tol:
             converged = True
         elif gain < eps_stall * max(err, 1e-300):
             break
+    B = B.to(cdtype)
     alpha = alpha.to(cdtype)
     amp = torch.linalg.norm(B, dim=1)
     modes = (B / amp[:, None].clamp_min(1e-300).to(cdtype)).T.contiguous()
     order = torch.argsort(-amp)
     return OptDMDResult(eigs=alpha[order], modes=modes[:, order], amplitudes=amp[order].to(rdtype),
                         rel_error=err, n_iter=n_iter, converged=converged,
-                        info={"errors": errs, "lambda": lam, "projections": n_proj})
+                        info={"errors": errs, "lambda": lam, "projections": n_proj,
+                              "route": "gram (K9 / K10 / K11)" if route["gram"] else "library"})
 
 
 def _match(reference: torch.Tensor, values: torch.Tensor) -> torch.Tensor:

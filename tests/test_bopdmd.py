@@ -228,3 +228,50 @@ def test_fit_is_the_optimum_an_independent_optimiser_finds():
     assert max(np.min(np.abs(got - a)) for a in ref) < 1e-6
     # and it IS a different point than the planted one (the noise moved the minimum)
     assert max(np.min(np.abs(ref - a)) for a in alpha) > 1e-4
+
+
+@pytest.mark.gpu
+def test_gram_route_pieces_match_torch_complex128():
+    """Round 3: one evaluation of the variable projection from ONE real product over the tall
+    matrices (interleaved (re, im) views on the fp64 MFMA kernel K9), the Hermitian solves on K10's
+    real embedding, the residual on K11 -- against plain torch complex128 at cfg5's size
+    (8760 x 200): B = Phi^+ H, the residual, and the Gauss-Newton matrix and gradient of the
+    library route (QR of Phi, explicit P W and W^H R)."""
+    rs = np.random.RandomState(2)
+    r, n = 200, 8760
+    t = np.arange(n) / 24.0
+    freq = np.sort(rs.uniform(0.02, 6.0, r // 2))
+    alpha = -rs.uniform(1e-4, 3e-3, r // 2) + 1j * 2 * np.pi * freq
+    alpha = np.concatenate([alpha, alpha.conj()])
+    modes = rs.standard_normal((r, r)) + 1j * rs.standard_normal((r, r))
+    H = np.exp(np.outer(t, alpha)) @ modes + 1e-2 * rs.standard_normal((n, r))
+    Hd = torch.from_numpy(H).cuda()
+    td = torch.from_numpy(t).cuda()
+    a = torch.from_numpy(alpha * (1 + 1e-4 * rs.standard_normal(r))).cuda()
+    kern = bop._gram_route(Hd)
+    assert kern is not None
+    ge = bop._GramEval(Hd, td, kern)
+    pc = ge.evaluate(a)
+    assert isinstance(pc, dict)
+    Phi = torch.exp(td[:, None].to(torch.complex128) * a[None, :])
+    Q, Rf = torch.linalg.qr(Phi)
+    B_ref = torch.linalg.solve_triangular(Rf, Q.conj().T @ Hd, upper=True)
+    R_ref = Hd - Phi @ B_ref
+    scale = float(B_ref.abs().max())
+    assert float((pc["B"] - B_ref).abs().max()) <= 1e-9 * scale
+    assert float((pc["R"] - R_ref).abs().max()) <= 1e-9 * float(Hd.abs().max())
+    assert abs(pc["err"] - float(torch.linalg.norm(R_ref) / torch.linalg.norm(Hd))) <= 1e-12
+    JtJ, g = ge.normal_matrix(pc)
+    W = td[:, None].to(torch.complex128) * Phi
+    PW = W - Q @ (Q.conj().T @ W)
+    C = W.conj().T @ R_ref
+    Ginv = torch.linalg.inv(Phi.conj().T @ Phi)
+    JtJ_ref = (PW.conj().T @ PW) * (B_ref.conj() @ B_ref.T) + Ginv * (C.conj() @ C.T)
+    g_ref = (C * B_ref.conj()).sum(dim=1)
+    assert float((JtJ - JtJ_ref).abs().max()) <= 1e-8 * float(JtJ_ref.abs().max())
+    assert float((g - g_ref).abs().max()) <= 1e-8 * float(g_ref.abs().max())
+    # the Levenberg-Marquardt system on K10's real embedding against the library's LU solve
+    dg = torch.diagonal(JtJ).real.to(torch.complex128)
+    d1 = ge.lm_step(JtJ, g, dg, 1.0)
+    d2 = torch.linalg.solve(JtJ + torch.diag(dg), g)
+    assert float((d1 - d2).abs().max()) <= 1e-9 * float(d2.abs().max())

@@ -10,6 +10,8 @@ OUT=$ROOT/gpurun_out/prof
 rm -rf "$OUT"; mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd "$ROOT"
+# (the full-width CPU sample is a ~200 s gesdd: off here, the profile run has to fit one gpurun call)
+export DMDX_BENCH_CPU_FULL=0
 BENCH="python3 bench.py --steps 3 --warmup 1"
 echo "[prof] plain bench"; $BENCH > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
 echo "[prof] kernel stats"
@@ -32,6 +34,10 @@ python3 scripts/bench_randomized.py > "$OUT/bench_randomized.json" 2> "$OUT/benc
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$OUT/stats_rand" --output-format csv -- python3 scripts/bench_randomized.py --steps 1 > "$OUT/stats_rand.log" 2>&1
 echo "[prof] gap-free (power-law) spectrum: the same step, kernel stats of the eigen stage"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$OUT/stats_powerlaw" --output-format csv -- python3 bench.py --steps 3 --warmup 1 --spectrum powerlaw --no-cpu-baseline --no-calibrate > "$OUT/stats_powerlaw.log" 2>&1
+echo "[prof] cfg4 (227.6 GB resident, randomized, 2 power iterations): kernel stats at rank 50 / 200, HBM traffic at rank 50"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$OUT/stats_cfg4_k50" --output-format csv -- python3 scripts/bench_cfg4.py --k 50 --quick > "$OUT/stats_cfg4_k50.log" 2>&1 || echo "[prof] cfg4 k50 stats failed"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$OUT/stats_cfg4_k200" --output-format csv -- python3 scripts/bench_cfg4.py --k 200 --quick > "$OUT/stats_cfg4_k200.log" 2>&1 || echo "[prof] cfg4 k200 stats failed"
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/pmc_cfg4_k50" --output-format csv -- python3 scripts/bench_cfg4.py --k 50 --quick > "$OUT/pmc_cfg4_k50.log" 2>&1 || echo "[prof] cfg4 k50 pmc failed"
 echo "[prof] summarize"
 python3 scripts/summarize_profiles.py "$OUT" "$ROOT/gpurun_out/profiles_$TAG" "$TAG"
 # the raw traces are large: keep only the small summaries + logs in gpurun_out/

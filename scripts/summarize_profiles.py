@@ -79,6 +79,34 @@ def main():
                 w = csv.DictWriter(g, fieldnames=list(rp[0].keys()))
                 w.writeheader()
                 w.writerows(rp[:25])
+    for sub in ("cfg4_k50", "cfg4_k200"):   # cfg4: top kernels of the (warm-up + one timed) randomized SVDs
+        fc = find(os.path.join(raw, "stats_" + sub), "kernel_stats.csv")
+        if fc:
+            rc = list(csv.DictReader(open(fc)))
+            rc.sort(key=lambda r: -float(r.get("TotalDurationNs", 0) or 0))
+            if rc:
+                with open(os.path.join(out, f"{tag}_{sub}_kernel_stats.csv"), "w", newline="") as g:
+                    w = csv.DictWriter(g, fieldnames=list(rc[0].keys()))
+                    w.writeheader()
+                    w.writerows(rc[:16])
+    fcp = find(os.path.join(raw, "pmc_cfg4_k50"), "counter_collection.csv")
+    if fcp:   # HBM-side traffic of the tall-skinny kernels at cfg4 (FETCH_SIZE in KB, doubled: gfx950 note)
+        per = {}
+        for r in csv.DictReader(open(fcp)):
+            if r["Counter_Name"] != "FETCH_SIZE":
+                continue
+            name = r["Kernel_Name"].split("(")[0][-60:]
+            a = per.setdefault(name, [0.0, set()])
+            a[0] += float(r["Counter_Value"])
+            a[1].add(r["Dispatch_Id"])
+        rows4 = sorted(((k, v[0], len(v[1])) for k, v in per.items()), key=lambda x: -x[1])[:8]
+        m4, n4 = 15573600, 3653
+        json.dump({"what": "rocprofv3 --pmc FETCH_SIZE over scripts/bench_cfg4.py --k 50 --quick (warm-up + one timed SVD = 2 SVDs, "
+                           "12 passes over X of 227.6 GB each)",
+                   "algorithmic_bytes_of_X_per_pass": 4.0 * m4 * n4,
+                   "kernels": [{"kernel": k, "FETCH_SIZE_KB_sum": v, "dispatches": c, "bytes_corrected": 2.0 * v * 1024,
+                                "passes_over_X_equiv": 2.0 * v * 1024 / (4.0 * m4 * n4)} for k, v, c in rows4]},
+                  open(os.path.join(out, f"{tag}_cfg4_k50_traffic.json"), "w"), indent=1)
     f, rows = kernel_stats(raw)
     rows.sort(key=lambda r: -float(r.get("TotalDurationNs", 0) or 0))
     top = rows[:12]

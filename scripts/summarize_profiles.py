@@ -6,13 +6,14 @@ usage: summarize_profiles.py <raw dir> <out dir> <tag>
 """
 import csv, glob, json, os, shutil, sys
 
-GRAM = "syrk_batch_kernel<true, 0>"                 # the cfg2 Gram launch (all 8 row blocks, LDS-DMA)
+GRAM = "syrk_batch_kernel<true, 0, 0>"              # the cfg2 Gram launch (all 8 row blocks, LDS-DMA, 128 x 128 tiles)
 M_BLOCK, N = 1038240, 8760                    # rows of X covered by one launch
 
 
 def find(d, suffix):
-    hits = sorted(glob.glob(os.path.join(d, "**", "*" + suffix), recursive=True))
-    return hits[0] if hits else None
+    # (the newest: a local gpurun_out/ accumulates the files of earlier collections)
+    hits = sorted(glob.glob(os.path.join(d, "**", "*" + suffix), recursive=True), key=os.path.getmtime)
+    return hits[-1] if hits else None
 
 
 def kernel_stats(raw):
@@ -95,7 +96,11 @@ def main():
         for r in csv.DictReader(open(fcp)):
             if r["Counter_Name"] != "FETCH_SIZE":
                 continue
-            name = r["Kernel_Name"].split("(")[0][-60:]
+            kn = r["Kernel_Name"]
+            name = next((k for k in ("skinny16_kernel", "skinny16_gram_reduce", "skinny_kernel", "syrk_batch_kernel", "xty_small_kernel",
+                                     "gemm_tn_reduce", "row_center_scale", "scale_columns") if k in kn), kn[:60])
+            if name in ("skinny16_kernel", "syrk_batch_kernel"):
+                name += kn[kn.index(name) + len(name):].split(">")[0] + ">"
             a = per.setdefault(name, [0.0, set()])
             a[0] += float(r["Counter_Value"])
             a[1].add(r["Dispatch_Id"])

@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256, WPS) void skinny16_kernel(
   DMDX_READ_STEP(0, 0);
 
   int cur = 0;
-  auto step = [&](auto kt, auto fast_tag, const bool has_next, auto& reload, auto& publish) {
+  auto step = [&](auto kt, auto fast_tag, const bool has_next, auto& reload, auto& publish, auto& early_store) {
     constexpr int k = decltype(kt)::value;
     // before the MFMAs of step k: the fragments of step k + 1 (the last step's successor is step 0 of
     // the next chunk, in the other stage: behind the barrier)
@@ -215,6 +215,9 @@ __global__ __launch_bounds__(256, WPS) void skinny16_kernel(
     }
     DMDX_MFMA_STEP(k);
     if constexpr ((k + 1) % NPART == 0) reload(k / NPART);   // the half's X registers are free: next chunk's
+    // W chunk c + 1 goes into the other stage in the MIDDLE of the chunk (nobody reads that stage between
+    // the previous barrier and the next one), so that no LDS store or load wait is pending at the barrier
+    if constexpr (k + 1 == NSTEP / 2) early_store();
   };
   auto chunk = [&](int c, auto fast_tag) {
     constexpr bool FAST = decltype(fast_tag)::value;
@@ -242,11 +245,13 @@ __global__ __launch_bounds__(256, WPS) void skinny16_kernel(
       }
       if constexpr (FAST) __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);
     };
-    auto publish = [&]() {   // W chunk c + 1 into the other stage; every wave is done reading this one
-#if defined(DMDX_K2_ABL) && (DMDX_K2_ABL & 4)   /* timing only: no W staging, no barrier */
+    auto early_store = [&]() {
+      if (has_next) store_w(cur ^ 1);
+    };
+    auto publish = [&]() {   // chunk c + 1 is in the other stage; every wave is done reading this one
+#if defined(DMDX_K2_ABL) && (DMDX_K2_ABL & 4)   /* timing only: no barrier */
       cur ^= 1;
 #else
-      if (has_next) store_w(cur ^ 1);
       __syncthreads();
       cur ^= 1;
 #endif
@@ -256,19 +261,19 @@ __global__ __launch_bounds__(256, WPS) void skinny16_kernel(
       else load_w(k0 + KB);
     }
     if constexpr (FAST) __builtin_amdgcn_sched_group_barrier(0x020, NPW, 0);
-    step(std::integral_constant<int, 0>{}, fast_tag, has_next, reload, publish);
-    step(std::integral_constant<int, 1>{}, fast_tag, has_next, reload, publish);
+    step(std::integral_constant<int, 0>{}, fast_tag, has_next, reload, publish, early_store);
+    step(std::integral_constant<int, 1>{}, fast_tag, has_next, reload, publish, early_store);
     if constexpr (NSTEP > 2) {
-      step(std::integral_constant<int, 2 % NSTEP>{}, fast_tag, has_next, reload, publish);
-      step(std::integral_constant<int, 3 % NSTEP>{}, fast_tag, has_next, reload, publish);
+      step(std::integral_constant<int, 2 % NSTEP>{}, fast_tag, has_next, reload, publish, early_store);
+      step(std::integral_constant<int, 3 % NSTEP>{}, fast_tag, has_next, reload, publish, early_store);
     }
     if constexpr (NSTEP > 4) {
-      step(std::integral_constant<int, 4 % NSTEP>{}, fast_tag, has_next, reload, publish);
-      step(std::integral_constant<int, 5 % NSTEP>{}, fast_tag, has_next, reload, publish);
+      step(std::integral_constant<int, 4 % NSTEP>{}, fast_tag, has_next, reload, publish, early_store);
+      step(std::integral_constant<int, 5 % NSTEP>{}, fast_tag, has_next, reload, publish, early_store);
     }
     if constexpr (NSTEP > 6) {
-      step(std::integral_constant<int, 6 % NSTEP>{}, fast_tag, has_next, reload, publish);
-      step(std::integral_constant<int, 7 % NSTEP>{}, fast_tag, has_next, reload, publish);
+      step(std::integral_constant<int, 6 % NSTEP>{}, fast_tag, has_next, reload, publish, early_store);
+      step(std::integral_constant<int, 7 % NSTEP>{}, fast_tag, has_next, reload, publish, early_store);
     }
   };
   int c = 0;

@@ -54,8 +54,19 @@ __global__ __launch_bounds__(256, WPS) void skinny16_kernel(
   constexpr int NP = C16 * (C16 + 1) / 2;
   constexpr int STG = NCOL * KB;                 // floats per W stage
   constexpr int G_FLOATS = GRAM ? NP * 256 : 0;
-  constexpr int LDS_FLOATS = 2 * STG > G_FLOATS ? 2 * STG : G_FLOATS;
+  constexpr int NST = 3;                          // W stages (see the counter hand-off below)
+  constexpr int LDS_FLOATS = (NST * STG > G_FLOATS ? NST * STG : G_FLOATS) + 4;
   __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+  // W chunks are handed from the four storing waves to the four reading waves WITHOUT s_barrier: a
+  // monotonic counter in LDS (the last word of the array) counts the waves that have stored their part
+  // of a chunk; chunk c is complete at 4 c.  A wave stores chunk c + 1 in the middle of chunk c and
+  // polls for it at the end of chunk c: the poll normally succeeds at once, so a wave that lags by
+  // less than half a chunk stalls nobody (one wave per SIMD at l > 112: nothing else covers a
+  // barrier's skew there -- the barrier + staging cost 9 % at l = 220).  Three stages make the
+  // write-after-read safe without a second counter: stage (c + 2) mod 3 is written during chunk
+  // c + 1 by waves that have seen chunk c + 1 complete, i.e. after every wave stored it in the middle
+  // of chunk c -- when all of them were done reading chunk c - 1's stage.
+  unsigned* fill_cnt = reinterpret_cast<unsigned*>(&lds[LDS_FLOATS - 4]);
 
   unsigned long long pc0 = 0, pr0 = 0;   // measurement aid (dmdx_set_clock_probe; null on the product path)
   if (clk != nullptr) {
@@ -193,6 +204,7 @@ __global__ __launch_bounds__(256, WPS) void skinny16_kernel(
   const int nchunks = (int)((n + KB - 1) / KB);
   f32x4 xq[2][4];   // X quads of the current chunk: [half g][s] = lane column k0 + 16 g + s + 4 kk
 
+  if (tid == 0) *fill_cnt = 0u;
   load_w(0);
   store_w(0);
 #pragma unroll
@@ -203,6 +215,7 @@ __global__ __launch_bounds__(256, WPS) void skinny16_kernel(
   DMDX_READ_STEP(0, 0);
 
   int cur = 0;
+  unsigned want = 0;   // 4 x (index of the chunk whose W is needed next)
   auto step = [&](auto kt, auto fast_tag, const bool has_next, auto& reload, auto& publish, auto& early_store) {
     constexpr int k = decltype(kt)::value;
     // before the MFMAs of step k: the fragments of step k + 1 (the last step's successor is step 0 of
@@ -245,16 +258,23 @@ __global__ __launch_bounds__(256, WPS) void skinny16_kernel(
       }
       if constexpr (FAST) __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);
     };
+    const int nxt = cur == NST - 1 ? 0 : cur + 1;
     auto early_store = [&]() {
-      if (has_next) store_w(cur ^ 1);
+      if (has_next) {
+        store_w(nxt);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's part of chunk c + 1 is in LDS ...
+        if (lane == 0) __hip_atomic_fetch_add(fill_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // ... before it says so
+      }
     };
-    auto publish = [&]() {   // chunk c + 1 is in the other stage; every wave is done reading this one
-#if defined(DMDX_K2_ABL) && (DMDX_K2_ABL & 4)   /* timing only: no barrier */
-      cur ^= 1;
-#else
-      __syncthreads();
-      cur ^= 1;
+    auto publish = [&]() {   // wait (normally not at all) until all four waves have stored chunk c + 1
+      want += 4u;
+#if !(defined(DMDX_K2_ABL) && (DMDX_K2_ABL & 4))   /* ABL 4, timing only: no hand-off */
+      if (has_next) {
+        while (__hip_atomic_load(fill_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < want) __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");
+      }
 #endif
+      cur = nxt;
     };
     if (has_next) {
       if constexpr (FAST) load_w_fast(k0 + KB);

@@ -552,12 +552,15 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(blocks[0], r, kern, args.cpu_baseline_rows, m, args.cpu_baseline_full)
         # The full-width sample SURVEY.md 8(d) asks for (all n columns: 17520 x 8760 at cfg2) costs ~7.4 x
-        # the half-width one (203.8 s against 27.8 s on the 128-thread box): taken by default when the
-        # half-width timing says it ends within ~4 minutes, so that the whole run stays inside the
-        # driver's limit; the half-width figures stay in the line next to it.
+        # the half-width one (203.8 s against 27.8 s on the 128-thread box).  The default run has to
+        # end within minutes and its CPU leg is meant to be 10-30 s of work, so the full-width sample
+        # is taken by default only when the half-width timing predicts <= 2 minutes for it (a faster
+        # host than the 128-thread boxes seen so far); `--cpu-baseline-full` (or
+        # DMDX_BENCH_CPU_FULL=2) takes it regardless -- profiles/r2_bench_cpu_full.json is such a run.
         half = out["cpu_baseline"]
         if (not args.cpu_baseline_full and args.workload == "cfg2" and os.environ.get("DMDX_BENCH_CPU_FULL", "1") != "0"
-                and args.cpu_baseline_rows is None and 7.5 * half["seconds"] <= 240.0):
+                and args.cpu_baseline_rows is None
+                and (7.5 * half["seconds"] <= 120.0 or os.environ.get("DMDX_BENCH_CPU_FULL") == "2")):
             full = cpu_baseline(blocks[0], r, kern, None, m, True)
             full["half_width_sample"] = {k: half[k] for k in ("value", "seconds", "sample", "parity", "randomized") if k in half}
             out["cpu_baseline"] = full

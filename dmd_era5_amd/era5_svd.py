@@ -181,8 +181,8 @@ def svd_on_era5(da, parsed_config: dict):
     U, s, V = svd_numpy(X, svd_type, n_components, **_engine_opts(parsed_config))
     if s.size and float(s[0]) > 0 and float(s[-1]) <= 1e-7 * float(s[0]):
         log_and_print(logger, "Singular values below 1e-7 s_1 are under the fp32 resolution of the data: their "
-                              "columns of U are returned as zeros (LAPACK returns arbitrary orthonormal "
-                              "vectors there).", level="warning")
+                              "columns of U are an arbitrary orthonormal completion (as LAPACK's are for zero "
+                              "singular values), not directions of the data.", level="warning")
     log_and_print(logger, f"{svd_type.capitalize()} SVD complete.")
     return U, s, V
 

@@ -919,6 +919,45 @@ def _eig_mean_deflated(G, w, musq, delay: int, l: int, eig_method: str, info: di
     return lam, V, lam_d, l
 
 
+def _complete_unit_rows(Ub, ok: torch.Tensor, comm: Comm) -> None:
+    """Left singular vectors whose singular value lies below the resolution of the data (s_j <=
+    1e-7 s_1 in fp32: their rows of the (k, M) factor came out as zeros) are replaced IN PLACE by
+    unit vectors orthogonal to the resolved ones and to each other -- what LAPACK returns for a
+    zero singular value (np.linalg.svd, era5_svd.py:251: any orthonormal completion; round 3: the
+    factor was left with zero columns before).  Random directions (seeded per rank: every rank
+    fills its own rows), two projections against the resolved rows, CholeskyQR2 among themselves;
+    the inner products are summed over the row blocks and the ranks in fp64.  Only ever runs on
+    (numerically) rank-deficient input, so plain torch products on the few rows involved."""
+    bad = torch.nonzero(~ok).squeeze(1)
+    nbad = int(bad.numel())
+    if nbad == 0:
+        return
+    good = torch.nonzero(ok).squeeze(1)
+    dev = Ub[0].device
+    gen = torch.Generator(device=dev).manual_seed(4321 + 7919 * int(comm.rank))
+    R = [torch.randn((nbad, U.shape[1]), generator=gen, device=dev, dtype=torch.float32) for U in Ub]
+    if good.numel():
+        Ug = [U[good] for U in Ub]
+        for _ in range(2):
+            C = torch.zeros((nbad, int(good.numel())), dtype=torch.float64, device=dev)
+            for Rb, Gb in zip(R, Ug):
+                C += Rb.double() @ Gb.double().T
+            comm.allreduce_sum_(C, tag="completion_allreduce")
+            for Rb, Gb in zip(R, Ug):
+                Rb -= (C @ Gb.double()).to(torch.float32)
+    for _ in range(2):
+        G = torch.zeros((nbad, nbad), dtype=torch.float64, device=dev)
+        for Rb in R:
+            G += Rb.double() @ Rb.double().T
+        comm.allreduce_sum_(G, tag="completion_allreduce")
+        L = torch.linalg.cholesky(0.5 * (G + G.T))
+        Linv = torch.linalg.solve_triangular(L, torch.eye(nbad, dtype=torch.float64, device=dev), upper=False)
+        for i, Rb in enumerate(R):
+            R[i] = (Linv @ Rb.double()).to(torch.float32)
+    for U, Rb in zip(Ub, R):
+        U[bad] = Rb
+
+
 @_magnitude_guard(with_mean=True)
 def svd_snapshots(Xt, n_components: int, delay: int = 1, oversample: int | None = None,
                   refine: bool = True, flip_sign: bool = True, comm: Comm | None = None,
@@ -1057,10 +1096,16 @@ def svd_snapshots(Xt, n_components: int, delay: int = 1, oversample: int | None 
             Rt = _pitched(kern, Rm.T.contiguous().to(torch.float32))
             Ub, whole = _project_blocks(kern, Up, Rt, delay)          # (k, d*mb)
             Vh = (V @ Z).T.contiguous()
+            if not bool(ok.all()):
+                _complete_unit_rows(Ub, ok, comm)
+                info["completed_directions"] = int((~ok).sum())
         else:
             s = s0[:k]
             Ub, whole = [U[:k] for U in Up], None
             Vh = V[:, :k].T.contiguous()
+            if not bool(good[:k].all()):
+                _complete_unit_rows(Ub, good[:k], comm)
+                info["completed_directions"] = int((~good[:k]).sum())
     finally:
         if mus is not None:
             for B, mu in zip(blocks, mus):
@@ -1513,6 +1558,12 @@ def svd_randomized(Xt, n_components: int, delay: int = 1, n_oversamples: int = 1
     Uk = _pitched(kern, Uk.T.contiguous().to(torch.float32))
     phase("small")
     Ub, whole = _project_blocks(kern, Qmb, Uk, delay, whole=U_out)   # U = Q Uhat = Y_1 (R_1^-1 Uhat)
+    # directions below the resolution of the data (exactly rank-deficient input: the shifted
+    # CholeskyQR leaves no orthonormal basis there): an orthonormal completion, as in svd_snapshots
+    ok = s[:k] > 1e-7 * s[0]
+    if not bool(ok.all()):
+        _complete_unit_rows(Ub, ok, comm)
+        info["completed_directions"] = int((~ok).sum())
     phase("project")
     if timings:
         info["phase_ms"] = {k_: v_ * 1e3 for k_, v_ in phase.acc.items()}

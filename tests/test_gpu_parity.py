@@ -1048,3 +1048,25 @@ def test_fp64_randomized_branch_follows_sklearns_normaliser(n_iter, norm):
     U, s, V = svd_numpy(X, "randomized", k, device="cuda", random_state=0, n_iter=n_iter, power_iteration_normalizer=norm)
     assert U.dtype == np.float64 and np.allclose(s, sr, rtol=1e-9)
     assert np.all(np.abs(np.sum(U * Ur, axis=0)) > 1 - 1e-8) and np.all(np.abs(np.sum(V * Vr, axis=1)) > 1 - 1e-8)
+
+
+@pytest.mark.parametrize("typ", ["standard", "randomized"])
+def test_rank_deficient_input_gets_an_orthonormal_completion(typ):
+    """An exactly rank-3 matrix asked for 6 components: s_4.. are zero to rounding; LAPACK (the
+    reference's np.linalg.svd) returns an arbitrary orthonormal completion of U there.  Round 3: so
+    does the engine (zero columns before): U^T U = I over all six columns, the three resolved
+    triplets are numpy's."""
+    from dmd_era5_amd.engine import svd_numpy
+
+    rs = np.random.RandomState(9)
+    m, n, k = 30000, 200, 6
+    X = (rs.standard_normal((m, 3)) * np.array([30.0, 10.0, 3.0])) @ rs.standard_normal((3, n))
+    X = X.astype(np.float32)
+    U, s, V = svd_numpy(X, typ, k, device="cuda:0", **({"random_state": 0} if typ == "randomized" else {}))
+    sr = np.linalg.svd(X.astype(np.float64), compute_uv=False)[:k]
+    assert np.allclose(s[:3], sr[:3], rtol=2e-5) and np.all(s[3:] < 1e-5 * s[0])
+    G = U.astype(np.float64).T @ U.astype(np.float64)
+    assert np.abs(G - np.eye(k)).max() < 5e-5
+    Ur = np.linalg.svd(X.astype(np.float64), full_matrices=False)[0][:, :3]
+    assert np.all(np.abs(np.sum(U[:, :3] * Ur, axis=0)) > 1 - 1e-5)
+    assert np.abs(V.astype(np.float64) @ V.astype(np.float64).T - np.eye(k)).max() < 5e-5

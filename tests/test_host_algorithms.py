@@ -117,15 +117,18 @@ def test_top_eigh_flat_spectrum_goes_to_the_full_solver_early():
 
 @pytest.mark.parametrize("shape", [(9, 2), (500, 30)])
 def test_all_zero_matrix_gives_zero_singular_values(shape):
-    """X = 0 (found by the sparse kind of the differential fuzz): s = 0, U = 0, V orthonormal, for
-    both types -- the range finder's CholeskyQR has nothing to factor and must not raise."""
+    """X = 0 (found by the sparse kind of the differential fuzz): s = 0, U and V orthonormal (round 3:
+    directions below the resolution of the data get an orthonormal completion, as LAPACK's U for
+    zero singular values; they were zero columns before), for both types -- the range finder's
+    CholeskyQR has nothing to factor and must not raise."""
     m, n = shape
     k = min(n, 5)
     for fn in (dsvd.svd_snapshots, dsvd.svd_randomized):
         kw = {"random_state": 0} if fn is dsvd.svd_randomized else {}
         r = fn(torch.zeros((n, m)), k, kern=K, **kw)
         assert r.s.shape == (k,) and float(r.s.abs().max()) == 0.0
-        assert float(r.Ut.abs().max()) == 0.0 and bool(torch.isfinite(r.Vh).all())
+        assert bool(torch.isfinite(r.Ut).all()) and bool(torch.isfinite(r.Vh).all())
+        assert torch.allclose(r.Ut.double() @ r.Ut.double().T, torch.eye(k, dtype=torch.float64), atol=1e-5)
         assert torch.allclose(r.Vh @ r.Vh.T, torch.eye(k, dtype=torch.float64), atol=1e-12)
 
 

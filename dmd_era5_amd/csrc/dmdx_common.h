@@ -46,6 +46,24 @@ int dmdx_device_cus();
 
 static inline bool dmdx_aligned16(const void* p) { return ((uintptr_t)p & 15u) == 0; }
 
+// Agent-scope (sc1: L1-bypassing, coherent across the XCDs' L2s) loads of data another workgroup stored
+// with sc1, as plain buffer loads: the compiler keeps any number of them in flight, where every
+// `__hip_atomic_load(..., AGENT)` is followed by its own `s_waitcnt vmcnt(0)` (16 column loads of a
+// Jacobi step = 16 round trips of ~1 us).  Ordering against the producer is the caller's barrier.
+// `rs` = dmdx_sc1_rsrc(base), offsets in bytes (< 2^31).
+#ifdef __HIPCC__
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t dmdx_sc1_rsrc(const void* base) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, -1, 0x00020000);
+}
+__device__ __forceinline__ double dmdx_ld_sc1_f64(__amdgpu_buffer_rsrc_t rs, int byte_off) {
+  typedef int i32x2 __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(double, (i32x2)__builtin_amdgcn_raw_buffer_load_b64(rs, byte_off, 0, 16 /* sc1 */));
+}
+__device__ __forceinline__ float dmdx_ld_sc1_f32(__amdgpu_buffer_rsrc_t rs, int byte_off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, byte_off, 0, 16 /* sc1 */));
+}
+#endif
+
 // K2, 16x16x4 body (skinny16.hip): l <= 256 columns in one pass, 16-column granular, optional fused Gram
 bool dmdx_skinny16_shape_ok(int64_t m, int64_t ldx);
 int dmdx_skinny16_launch(const float* X, int64_t m, int64_t n, int64_t ldx, const float* W, int64_t ldw, int l, float* Y,

@@ -135,6 +135,8 @@ __global__ __launch_bounds__(JTH) void jacobi_svd_kernel(JacobiParams p) {
   unsigned epoch = 0;
   bool alive = true, converged = false;
   int sweep = 0;
+  const __amdgpu_buffer_rsrc_t crs = dmdx_sc1_rsrc(p.C);
+  const int ldcb = (int)p.ldc * 8;
 
   for (; sweep < JMAX_SWEEPS && alive; ++sweep) {
     int rotated_wg = 0;
@@ -152,13 +154,20 @@ __global__ __launch_bounds__(JTH) void jacobi_svd_kernel(JacobiParams p) {
         const int cp = bp * JW + wave, cq = bq * JW + wave;
         double* dp = cols + wave * LD;
         double* dq = cols + (JW + wave) * LD;
-        const double* sp = p.C + (int64_t)cp * p.ldc;
-        const double* sq = p.C + (int64_t)cq * p.ldc;
+        // all 2 NR loads in flight together (offsets clamped into the matrix, the value masked afterwards)
+        const int op = (cp < n ? cp : 0) * ldcb, oq = (cq < n ? cq : 0) * ldcb;
+        double vp[NR], vq[NR];
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+          const int r = lane + 64 * i, rc = r < n ? r : n - 1;
+          vp[i] = dmdx_ld_sc1_f64(crs, op + 8 * rc);
+          vq[i] = dmdx_ld_sc1_f64(crs, oq + 8 * rc);
+        }
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
           const int r = lane + 64 * i;
-          dp[r] = (cp < n && r < n) ? ld_cc(sp + r) : 0.0;
-          dq[r] = (cq < n && r < n) ? ld_cc(sq + r) : 0.0;
+          dp[r] = (cp < n && r < n) ? vp[i] : 0.0;
+          dq[r] = (cq < n && r < n) ? vq[i] : 0.0;
         }
       }
       __syncthreads();
@@ -222,12 +231,16 @@ __global__ __launch_bounds__(JTH) void jacobi_svd_kernel(JacobiParams p) {
     for (int h = 0; h < 2; ++h) {
       const int c = (2 * wg + h) * JW + wave;
       if (c < n) {
-        const double* src = p.C + (int64_t)c * p.ldc;
-        double ss = 0.0;
-        for (int r = lane; r < n; r += 64) {
-          const double v = ld_cc(src + r);
-          ss = fma(v, v, ss);
+        double v[NR];
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+          const int r = lane + 64 * i;
+          v[i] = dmdx_ld_sc1_f64(crs, c * ldcb + 8 * (r < n ? r : n - 1));
         }
+        double ss = 0.0;
+#pragma unroll
+        for (int i = 0; i < NR; ++i)
+          if (lane + 64 * i < n) ss = fma(v[i], v[i], ss);
         ss = wave_sum(ss);
         if (lane == 0) st_cc(&p.snorm[c], sqrt(ss));
       }
@@ -255,9 +268,16 @@ __global__ __launch_bounds__(JTH) void jacobi_svd_kernel(JacobiParams p) {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) rank += __shfl_xor(rank, off, 64);
     const double inv = mine > 0.0 ? 1.0 / mine : 0.0;
-    const double* src = p.C + (int64_t)c * p.ldc;
     double* dst = p.Zt + (int64_t)rank * p.ldz;
-    for (int r = lane; r < n; r += 64) dst[r] = ld_cc(src + r) * inv;
+    double v[NR];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      const int r = lane + 64 * i;
+      v[i] = dmdx_ld_sc1_f64(crs, c * ldcb + 8 * (r < n ? r : n - 1));
+    }
+#pragma unroll
+    for (int i = 0; i < NR; ++i)
+      if (lane + 64 * i < n) dst[lane + 64 * i] = v[i] * inv;
     if (lane == 0) p.sigma[rank] = mine;
   }
 }
@@ -278,6 +298,7 @@ extern "C" int dmdx_svd_jacobi_f64(double* C, int64_t n, int64_t ldc, double* si
   DMDX_CHECK_ARG(C && sigma && Zt, "svd_jacobi: null pointer");
   DMDX_CHECK_ARG(n >= 2 && n <= JMAXN, "svd_jacobi: n = %lld outside [2, %d]", (long long)n, JMAXN);
   DMDX_CHECK_ARG(ldc >= n && ldz >= n, "svd_jacobi: leading dimension smaller than n");
+  DMDX_CHECK_ARG(ldc <= (int64_t(1) << 17), "svd_jacobi: ldc = %lld beyond the 32-bit byte offsets of the column loads", (long long)ldc);
   DMDX_CHECK_ARG(Zt != C, "svd_jacobi: Zt must not alias C");
   const size_t need = dmdx_svd_jacobi_workspace_bytes(n);
   if (workspace == nullptr || workspace_bytes < need) {

@@ -352,6 +352,24 @@ def _eigh_desc(T: torch.Tensor, kern=None):
     return torch.flip(th, dims=(0,)), torch.flip(Z, dims=(1,))
 
 
+def _smallest_eig_estimate(T: torch.Tensor, kern, gen, iters: int = 8) -> torch.Tensor:
+    """An estimate (from above: a Rayleigh quotient) of the smallest eigenvalue of the small SPD matrix
+    T, as a 0-d device tensor: ``iters`` steps of inverse iteration through K10's explicit L^-1
+    (0.7 ms at 188 columns where the full Jacobi solve it replaces took 3.7 ms of the rank-200 eigen
+    stage).  Only the filter's cut is taken from it, and any cut between the block's smallest Ritz
+    value and the wanted ones filters correctly; the library solver answers when T is not
+    numerically positive definite."""
+    if kern is not None and 2 <= T.shape[0] <= getattr(kern, "chol_max_n", 0):
+        L, Linv, info = _chol(kern, T)
+        if _chol_ok(info):
+            v = torch.randn((T.shape[0], 1), dtype=T.dtype, generator=gen, device=T.device)
+            for _ in range(iters):
+                v = Linv.T @ (Linv @ v)
+                v = v / torch.linalg.vector_norm(v).clamp_min(1e-300)
+            return torch.nan_to_num((v.T @ (T @ v)).reshape(()), nan=math.inf)   # (a NaN would win torch.minimum)
+    return _eigh_desc(T, kern)[0][-1]
+
+
 def _svd_wide(Bm: torch.Tensor, kern=None):
     """Thin SVD of the wide l x n fp64 matrix B = Q^T X of the randomized path (extmath.py:579) ->
     (Uhat (l, l), s (l,) descending, Vh (l, n)).  The library's gesvd is launch-rate bound with host
@@ -586,8 +604,7 @@ def top_eigh(G: torch.Tensor, l: int, method: str = "auto", tol: float = 1e-9,
         GW = gq(W)
         products += 2
         Tw = _tn(kern, W, GW)
-        thw, _ = _eigh_desc(0.5 * (Tw + Tw.T), kern)
-        cut_w = torch.minimum(thw[-1], th[b - 1]).clamp_min(0.0)
+        cut_w = torch.minimum(_smallest_eig_estimate(0.5 * (Tw + Tw.T), kern, gen), th[b - 1]).clamp_min(0.0)
         Q = torch.cat([Q, W], dim=1)
         th = torch.cat([th, cut_w.expand(b2 - b)])
         resv = torch.cat([resv, torch.zeros(b2 - b, dtype=resv.dtype, device=resv.device)])

@@ -272,8 +272,15 @@ def lat_band(nlat: int, rank: int, world: int) -> tuple[int, int]:
     return rank * nlat // world, (rank + 1) * nlat // world
 
 
-def _upload_variable(da: DataArray, level_idx, take, device, kern, center, scale, stats, band=None):
+def _upload_variable(da: DataArray, level_idx, take, device, kern, center, scale, stats, band=None, pad4=False):
     """One variable (time, level, lat, lon) -> centred/scaled row blocks (time, rows) in HBM.
+
+    ``pad4``: a variable whose number of space points is not a multiple of 4 (a grid with an odd
+    number of longitudes and latitudes) gets its last row block widened by 1-3 all-zero space points,
+    so that every block keeps the 16-byte-aligned leading dimension the LDS-DMA / 16-byte-load bodies of
+    K1 / K2 / K3 need (the register-staged bodies they otherwise fall to are 1.3-1.4x slower).  Zero
+    rows change neither X^T X nor the singular values, and their rows of U are exactly zero; the
+    caller drops them (returned widths are the padded ones, ``m_v`` the true count).
 
     Streams time slabs: file/host -> pinned staging -> device slab -> strided device copy
     into each row block.  Row order inside the variable: level slowest, longitude fastest.
@@ -293,7 +300,8 @@ def _upload_variable(da: DataArray, level_idx, take, device, kern, center, scale
     whole = (i0, i1) == (0, nlat_all)
     m_v = len(level_idx) * nlat * nlon
     ranges = dsvd.split_rows(m_v)
-    blocks = [torch.empty((n, b - a), dtype=torch.float32, device=device) for a, b in ranges]
+    blocks = [torch.zeros((n, b - a + (-(b - a)) % 4), dtype=torch.float32, device=device) if pad4 and (b - a) % 4
+              else torch.empty((n, b - a), dtype=torch.float32, device=device) for a, b in ranges]
     lazy = da.lazy
     host = None if lazy is not None else da.values
     rows = max(1, SLAB_BYTES // max(1, nlev_all * max(nlat, 1) * nlon * 4))
@@ -344,14 +352,14 @@ def _upload_variable(da: DataArray, level_idx, take, device, kern, center, scale
             nbytes += slab.nbytes
             dev = torch.from_numpy(slab).to(device, non_blocking=False)
         for (a, b), Xb in zip(ranges, blocks):
-            Xb[j0:j1].copy_(dev[:, a:b])
+            Xb[j0:j1, : b - a].copy_(dev[:, a:b])
         if direct and on_gpu:
             events[it & 1] = torch.cuda.Event()
             events[it & 1].record()
         del dev
-    for Xb in blocks:
+    for (a, b), Xb in zip(ranges, blocks):
         if center:
-            mu, sd = kern.row_center_scale_(Xb, bool(scale))
+            mu, sd = kern.row_center_scale_(Xb[:, : b - a], bool(scale))   # (the zero rows stay zero: 0 / 0 otherwise)
             stats["mean"].append(mu)
             if scale:
                 stats["std"].append(sd)
@@ -499,10 +507,13 @@ def _device_pipeline(ds: Dataset, parsed_config: dict, comm=None, kern=None, dev
         prime_min = int(os.environ.get("DMDX_PRIME_MIN_BYTES", str(1 << 30)))
         primer = _prime_async(device, parsed_config["svd_type"]) if device.type == "cuda" and \
             4 * rows * len(take) >= prime_min else None
-        stats, total = {"mean": [], "std": []}, 0
+        stats, total, true_rows = {"mean": [], "std": []}, 0, []
         for name in names:
-            vb, _, nbytes = _upload_variable(ds[name], level_idx, take, device, kern, center, scale, stats, band)
+            # (a tall problem on a grid whose space-point count is not a multiple of 4: 1-3 zero rows per variable)
+            vb, m_v, nbytes = _upload_variable(ds[name], level_idx, take, device, kern, center, scale, stats, band,
+                                               pad4=not wide)
             blocks.extend(vb)
+            true_rows.extend(b - a for a, b in dsvd.split_rows(m_v))
             total += nbytes
         if primer is not None:
             primer.join()
@@ -548,6 +559,18 @@ def _device_pipeline(ds: Dataset, parsed_config: dict, comm=None, kern=None, dev
         log_and_print(logger, "Performing randomized SVD...")
         res = dsvd.svd_randomized(blocks, k, delay=d, comm=comm, kern=kern, **_engine_opts(parsed_config))
         log_and_print(logger, "Randomized SVD complete.")
+    if not stream_bytes and any(int(b.shape[1]) != r for b, r in zip(blocks, true_rows)):
+        # drop the zero rows the ingest appended (their rows of U are exactly zero); from here on the
+        # blocks are the narrow views again
+        Mp = sum(int(b.shape[1]) for b in blocks)
+        keep, off = [], 0
+        for b, r in zip(blocks, true_rows):
+            keep.append(torch.arange(off, off + r, device=device))
+            off += int(b.shape[1])
+        kk_ = res.Ut.shape[0]
+        Ut = res.Ut.reshape(kk_, d, Mp).index_select(2, torch.cat(keep)).reshape(kk_, -1)
+        res = dsvd.SvdResult(Ut=Ut, s=res.s, Vh=res.Vh, info=res.info)
+        blocks = [b[:, :r] for b, r in zip(blocks, true_rows)]
     sync()
     dt = _time.perf_counter() - t0
     if not stream_bytes:

@@ -699,12 +699,11 @@ def _pitched(kern, Wt: torch.Tensor) -> torch.Tensor:
 
 
 def split_rows(m: int, block_rows: int | None = None) -> list[tuple[int, int]]:
-    """[(start, stop)] of nearly equal row blocks, each a multiple of 4 rows when m is."""
+    """[(start, stop)] of nearly equal row blocks, each a multiple of 4 rows -- except the last one
+    when m is not (the ingest pads that one with zero rows, era5_svd._upload_variable)."""
     block_rows = block_rows or BLOCK_ROWS
     nb = max(1, -(-m // block_rows))
-    base = -(-m // nb)
-    if m % 4 == 0:
-        base = -(-base // 4) * 4
+    base = -(-(-(-m // nb)) // 4) * 4
     out, r = [], 0
     while r < m:
         out.append((r, min(m, r + base)))

@@ -561,3 +561,57 @@ def test_main_with_the_library_primer_on_a_side_thread(svd_base_config, project_
     assert started and started[0] is not None and not started[0].is_alive()
     for name in ("U", "s", "V"):
         assert np.array_equal(on[name].values, off[name].values), name
+
+
+@pytest.mark.parametrize("svd_type,d,scale", [("standard", 1, False), ("standard", 2, True), ("randomized", 1, False)])
+def test_main_on_a_grid_whose_point_count_is_not_a_multiple_of_four(svd_base_config, project_root, monkeypatch, svd_type, d, scale):
+    """35 x 71 grid points x 2 levels = 4970 space points per variable (4970 % 4 = 2): the ingest
+    appends two zero space points per variable so that the aligned kernel bodies run, and main()
+    must give back exactly the rows of the reference pipeline (no trace of the padding in U, X,
+    X_mean or the labels)."""
+    from dmd_era5_amd import era5_svd, io_netcdf
+    from dmd_era5_amd.config_parser import config_parser
+    from dmd_era5_amd.create_mock_data import add_download_attributes, create_mock_era5
+    from dmd_era5_amd.labeled import Coord, DataArray, Dataset
+
+    cfg = dict(svd_base_config, start_datetime="2019-01-01T00", end_datetime="2019-01-03T00",
+               variables="temperature,u_component_of_wind", levels="1000,850", svd_type=svd_type,
+               mean_center=True, scale=scale, delay_embedding=d, n_components=5,
+               save_data_matrix=True, svd_seed=0)
+    p = config_parser(cfg, "era5-svd")
+    full = create_mock_era5(cfg["start_datetime"], cfg["end_datetime"], p["variables"], p["levels"], seed=11, dtype=np.float32)
+    cds = {"time": full.coords["time"], "level": full.coords["level"],
+           "latitude": Coord("latitude", full.coords["latitude"].values[:35]),
+           "longitude": Coord("longitude", full.coords["longitude"].values[:71])}
+    ds = Dataset(coords=cds, attrs=dict(full.attrs))
+    for name in p["variables"]:
+        ds[name] = DataArray(np.ascontiguousarray(full[name].values[:, :, :35, :71]), full[name].dims, cds, dict(full[name].attrs))
+    io_netcdf.to_netcdf(add_download_attributes(ds, p), p["era5_slice_path"])
+
+    seen = []
+    real = era5_svd._upload_variable
+    monkeypatch.setattr(era5_svd, "_upload_variable",
+                        lambda *a, **k: (lambda out: (seen.append([int(b.shape[1]) for b in out[0]]), out)[1])(real(*a, **k)))
+    res, _, _ = era5_svd.main(cfg, write_to_netcdf=False)
+    assert seen == [[4972], [4972]]                      # the blocks the kernels saw were padded
+
+    variables = {k: ds[k].values for k in p["variables"]}
+    X, X_mean, X_std = orc.preprocess(variables, True, scale, d)
+    m = X.shape[0]
+    assert m == d * 2 * 4970 and res["U"].shape == (m, 5) and res["X"].shape == X.shape
+    assert np.allclose(res["X"].values, X, rtol=0, atol=2e-4 * (1 if scale else 30))
+    if svd_type == "standard":
+        Uo, so, Vo = orc.svd_standard(X.astype(np.float64), 5)
+        assert np.allclose(res["s"].values, so, rtol=2e-5)
+        rec = (res["U"].values.astype(np.float64) * res["s"].values) @ res["V"].values
+        assert np.linalg.norm(rec - (Uo * so) @ Vo) <= 2e-3 * np.linalg.norm((Uo * so) @ Vo)
+    else:
+        Ur, sr, Vr = orc.svd_randomized(X, 5, random_state=0)
+        assert np.allclose(res["s"].values, sr, rtol=1e-3)
+    U = res["U"].values.astype(np.float64)
+    assert np.abs(U.T @ U - np.eye(5)).max() < 1e-4
+    assert np.array_equal(res.coords["space"].values, np.arange(m))
+    if d > 1:
+        assert np.allclose(res["X_mean"].values, X_mean, rtol=1e-5, atol=2e-4)
+        if scale:
+            assert np.allclose(res["X_std"].values, X_std, rtol=1e-5)

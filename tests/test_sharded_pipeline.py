@@ -245,3 +245,72 @@ def test_streaming_uncentred_standard_svd_deflates_the_time_mean(tmp_path, d, wo
     assert np.allclose(s, s1, rtol=2e-6)
     for j in range(3):
         assert abs(np.dot(U[:, j], U1[:, j])) > 1 - 1e-6 and abs(np.dot(V[j], V1[j])) > 1 - 1e-6
+
+
+@pytest.mark.parametrize("svd_type,d,scale,world", [("standard", 1, False, 1), ("standard", 2, True, 2), ("randomized", 2, False, 1)])
+def test_grid_with_a_point_count_that_is_not_a_multiple_of_four(tmp_path, svd_type, d, scale, world):
+    """35 x 71 grid points: every variable has 3 x 2485 = 7455 space points (7455 % 4 = 3; the two
+    latitude bands of the sharded case 17 x 71 x 3 = 3621 and 18 x 71 x 3 = 3834, % 4 = 1 and 2).
+    The ingest widens the last row block of every variable with zero space points so that the
+    aligned kernel bodies run; U, X, X_mean and X_std must come back in the reference's row order
+    without them, and equal to numpy's SVD of the returned data matrix."""
+    from dmd_era5_amd import hdf5_lite, io_netcdf
+    from dmd_era5_amd import svd as dsvd
+    from dmd_era5_amd.create_mock_data import create_mock_era5
+    from dmd_era5_amd.labeled import Coord, DataArray, Dataset
+
+    if not hdf5_lite.available():
+        pytest.skip("libhdf5 not found")
+    full = create_mock_era5("2019-01-01", "2019-01-03", ["temperature", "u_component_of_wind"], [1000, 850, 500],
+                            seed=21, dtype=np.float32)
+    t = np.arange(49, dtype=np.float64)[:, None, None, None]
+    lat = np.radians(full.coords["latitude"].values[:35])[None, None, :, None]
+    lon = np.radians(full.coords["longitude"].values[:71])[None, None, None, :]
+    cds = {"time": full.coords["time"], "level": full.coords["level"],
+           "latitude": Coord("latitude", full.coords["latitude"].values[:35]),
+           "longitude": Coord("longitude", full.coords["longitude"].values[:71])}
+    ds = Dataset(coords=cds, attrs=dict(full.attrs))
+    for v, name in enumerate(full.data_vars):
+        f = full[name].values[:, :, :35, :71].astype(np.float64)
+        f = f + 60 * np.sin(2 * np.pi * t / 24) * np.cos(lat) * np.cos(lon + v) + 35 * np.cos(2 * np.pi * t / 11) * np.sin(2 * lat) * np.sin(2 * lon)
+        f = f + 20 * (t / 49.0) ** 2 * np.cos(3 * lon) * np.ones_like(lat)
+        ds[name] = DataArray(np.ascontiguousarray(f.astype(np.float32)), full[name].dims, cds, dict(full[name].attrs))
+    path = str(tmp_path / "odd.nc")
+    os.environ["DMDX_NETCDF_BACKEND"] = "hdf5"
+    io_netcdf.to_netcdf(ds, path)
+    cfg = _cfg(svd_type, d, True, scale, None)
+    if world == 1:
+        U, s, V, coords, X, Xm, Xs = _run(path, cfg, dsvd.Comm())
+        X, Xm, Xs = X.values, (None if Xm is None else Xm.values), (None if Xs is None else Xs.values)
+    else:
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_worker, args=(r, world, port, path, cfg, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        got = [q.get(timeout=180) for _ in range(world)]
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        U, s, V, X, Xm, Xs, _ = next(g for g in got if g is not None)
+    m1 = 2 * 3 * 35 * 71
+    assert U.shape == (d * m1, 3) and X.shape == (d * m1, 49 - d + 1)
+    # the data matrix: the reference's standardisation and embedding order, from the raw fields
+    raw = np.concatenate([ds[name].values.reshape(49, -1).T for name in ds.data_vars], axis=0).astype(np.float64)
+    mu = raw.mean(axis=1, keepdims=True)
+    Z = raw - mu
+    sd = Z.std(axis=1, keepdims=True)
+    if scale:
+        Z = Z / sd
+    E = np.concatenate([Z[:, k:k + 49 - d + 1] for k in range(d)], axis=0)
+    assert np.allclose(X, E, rtol=0, atol=3e-4 * np.abs(E).max())
+    if d > 1:
+        assert np.allclose(Xm, np.tile(mu[:, 0], d), rtol=1e-5, atol=1e-3)
+        if scale:
+            assert np.allclose(Xs, np.tile(sd[:, 0], d), rtol=1e-4)
+    Un, sn, Vn = np.linalg.svd(E, full_matrices=False)
+    assert np.allclose(s, sn[:3], rtol=1e-4 if svd_type == "standard" else 2e-3)
+    for j in range(3):
+        assert abs(np.dot(U[:, j], Un[:, j])) > 1 - 1e-3 and abs(np.dot(V[j], Vn[j])) > 1 - 1e-3
+    assert np.abs(U.T @ U - np.eye(3)).max() < 1e-4

@@ -771,6 +771,27 @@ Plan make_plan(int64_t K, int64_t nrow, int64_t ncol, int syrk, int share = 1) {
   if (want > maxs) want = maxs;
   if (want < 1) want = 1;
   if (want > 256) want = 256;
+  // The tail of the launch: its units are equally long and 512 of them are resident, so a launch of
+  // r = units / 512 rounds takes ceil(r) of them -- 6.34 rounds (X^T Y of 16 cfg4 blocks, l = 70: 29 tiles x 7
+  // splits x 16) cost 7.  With few rounds, take the split count (up to twice the wanted one) that fills the
+  // last round best; the first one that fills it to 97 % wins.  (The Gram of cfg2 runs 75 rounds: unchanged.)
+  // Only when the wanted count leaves the last round less than 92 % full: measured on 16 cfg4 blocks
+  // (n = 3653) l = 70 11.58 -> 11.09 ms, l = 100 15.14 -> 14.24, l = 220 30.07 -> 27.95; on 8 cfg2 blocks
+  // (n = 8760, last round 92.4 % full as it is) twice the splits cost 2 % (l = 60 10.60 -> 10.82 ms).
+  if (getenv("DMDX_TN_NO_TAILFIT") == nullptr) {
+    auto fill = [&](int64_t w) {
+      const int64_t cps = (pl.chunks_total + w - 1) / w;
+      const int64_t ns = (pl.chunks_total + cps - 1) / cps;
+      const double r = (double)(per_split * ns) / 512.0;
+      return r / (double)(int64_t)(r + 0.999999);
+    };
+    int64_t best = want;
+    double bf = fill(want);
+    if (bf < 0.92)
+      for (int64_t w = want + 1; bf < 0.97 && w <= maxs && w <= 256 && w <= 2 * want + 2; ++w)
+        if (fill(w) > bf) { bf = fill(w); best = w; }
+    want = best;
+  }
   pl.chunks_per_split = (int)((pl.chunks_total + want - 1) / want);
   pl.nsplit = (pl.chunks_total + pl.chunks_per_split - 1) / pl.chunks_per_split;
   pl.ws_bytes = (size_t)pl.nsplit * pl.ntiles * pl.tm * BT * sizeof(double);
@@ -1090,6 +1111,22 @@ void xty_small_plan(const int64_t* K, int nb_, int ntiles, int* chunks, int* cps
     const int64_t maxs = chunks[j] / 16 > 0 ? chunks[j] / 16 : 1;
     if (want > maxs) want = maxs;
     if (want < 1) want = 1;
+    // (the tail of the launch, as in make_plan: cfg2 at l = 20 is 69 tiles x 8 blocks x 4 splits = 4.31
+    // rounds of 512 that cost 5; 12 splits are 12.94)
+    if (getenv("DMDX_TN_NO_TAILFIT") == nullptr) {
+      auto fill = [&](int64_t w) {
+        const int64_t cps_ = (chunks[j] + w - 1) / w;
+        const int64_t ns = cps_ > 0 ? (chunks[j] + cps_ - 1) / cps_ : 0;
+        const double r = (double)((int64_t)ntiles * nb_ * ns) / 512.0;
+        return r > 0.0 ? r / (double)(int64_t)(r + 0.999999) : 1.0;
+      };
+      int64_t best = want;
+      double bf = fill(want);
+      if (bf < 0.92)
+        for (int64_t w = want + 1; bf < 0.97 && w <= maxs && w <= 4 * want + 2; ++w)
+          if (fill(w) > bf) { bf = fill(w); best = w; }
+      want = best;
+    }
     cps[j] = (int)((chunks[j] + want - 1) / want);
     // a block of fewer than 64 rows has no full chunk: no units here, all of it goes to the tail launch
     nsplit[j] = cps[j] > 0 ? (chunks[j] + cps[j] - 1) / cps[j] : 0;

@@ -38,6 +38,7 @@ echo "[prof] cfg4 (227.6 GB resident, randomized, 2 power iterations): kernel st
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$OUT/stats_cfg4_k50" --output-format csv -- python3 scripts/bench_cfg4.py --k 50 --quick > "$OUT/stats_cfg4_k50.log" 2>&1 || echo "[prof] cfg4 k50 stats failed"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$OUT/stats_cfg4_k200" --output-format csv -- python3 scripts/bench_cfg4.py --k 200 --quick > "$OUT/stats_cfg4_k200.log" 2>&1 || echo "[prof] cfg4 k200 stats failed"
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/pmc_cfg4_k50" --output-format csv -- python3 scripts/bench_cfg4.py --k 50 --quick > "$OUT/pmc_cfg4_k50.log" 2>&1 || echo "[prof] cfg4 k50 pmc failed"
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE -d "$OUT/pmc_cfg4_sq" --output-format csv -- python3 scripts/bench_cfg4.py --k 50 --quick > "$OUT/pmc_cfg4_sq.log" 2>&1 || echo "[prof] cfg4 k50 sq pmc failed"
 echo "[prof] summarize"
 python3 scripts/summarize_profiles.py "$OUT" "$ROOT/gpurun_out/profiles_$TAG" "$TAG"
 # the raw traces are large: keep only the small summaries + logs in gpurun_out/

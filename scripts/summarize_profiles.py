@@ -112,6 +112,32 @@ def main():
                    "kernels": [{"kernel": k, "FETCH_SIZE_KB_sum": v, "dispatches": c, "bytes_corrected": 2.0 * v * 1024,
                                 "passes_over_X_equiv": 2.0 * v * 1024 / (4.0 * m4 * n4)} for k, v, c in rows4]},
                   open(os.path.join(out, f"{tag}_cfg4_k50_traffic.json"), "w"), indent=1)
+    fsq = find(os.path.join(raw, "pmc_cfg4_sq"), "counter_collection.csv")
+    if fsq:   # matrix-core occupancy of the tall-skinny kernels at cfg4 (per kernel family, summed over its dispatches)
+        acc = {}
+        for r in csv.DictReader(open(fsq)):
+            kn = r["Kernel_Name"]
+            name = next((k for k in ("skinny16_kernel", "syrk_batch_kernel", "xty_small_kernel") if k in kn), None)
+            if name is None:
+                continue
+            name += kn[kn.index(name) + len(name):].split(">")[0] + ">"
+            a = acc.setdefault(name, {"dispatches": set()})
+            a[r["Counter_Name"]] = a.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+            a["dispatches"].add(r["Dispatch_Id"])
+        outk = []
+        for name, a in acc.items():
+            gui = a.get("GRBM_GUI_ACTIVE", 0.0)
+            if gui <= 0:
+                continue
+            outk.append({"kernel": name, "dispatches": len(a["dispatches"]),
+                         "mfma_busy_frac": a.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (gui / 8 * 1024),
+                         "lds_bank_conflict_frac_of_lds_active": (a.get("SQ_LDS_BANK_CONFLICT", 0.0) / a["SQ_LDS_IDX_ACTIVE"])
+                         if a.get("SQ_LDS_IDX_ACTIVE") else None,
+                         "gpu_active_cycles_per_xcd": gui / 8})
+        outk.sort(key=lambda d: -d["gpu_active_cycles_per_xcd"])
+        json.dump({"what": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE over "
+                           "scripts/bench_cfg4.py --k 50 --quick; mfma_busy_frac = busy cycles / (active cycles x 1024 SIMDs)",
+                   "kernels": outk[:6]}, open(os.path.join(out, f"{tag}_cfg4_k50_sq.json"), "w"), indent=1)
     f, rows = kernel_stats(raw)
     rows.sort(key=lambda r: -float(r.get("TotalDurationNs", 0) or 0))
     top = rows[:12]

@@ -197,9 +197,11 @@ __device__ unsigned long long dmdx_stamp[8];
 // lds: 2 stages of (TM + 128) x 32 floats.
 // H16 (round 3): one more 16-row block below the SK 32-row blocks, on v_mfma_f32_16x16x4_f32 (same flop
 //   rate, half the rows): tile heights 48 / 80 / 112, so that l = 70 columns of Y (BASELINE config 4:
-//   rank 50 + 20 oversamples) run 80 rows instead of 96.  Its fragments are 8-byte reads (lane
-//   (i = lane & 15, kk = lane >> 4) takes k = 8 t + 2 kk + {0, 1} of its column: two MFMAs per k-step
-//   and 16-column half of the wave's 32 columns), conflict-free under the same swizzle.
+//   rank 50 + 20 oversamples) run 80 rows instead of 96.  Its fragments are 16-byte reads, one per operand
+//   and half chunk (lane (i = lane & 15, kk = lane >> 4) takes the piece 4 u + kk of its column: MFMA e
+//   contracts k = 16 u + 4 kk + e, two MFMAs per k-step and 16-column half of the wave's 32 columns).
+//   (8-byte reads per k-step -- the first version -- were two-way bank-conflicted: columns 2j and 2j + 1
+//   share a bank group under the piece swizzle; PMC: 27 % of the LDS-active cycles.)
 template <bool DMA, int ABL, int SK, int H16 = 0>
 __device__ __forceinline__ void tn_unit(const TnParams& p, const int split, const int row0, const int col0,
                                         double* Pt, float* lds) {
@@ -430,23 +432,27 @@ __device__ __forceinline__ void tn_unit(const TnParams& p, const int split, cons
   // LDS while the 16 MFMAs of k-step t run.  Lane (r = lane&31, h = lane>>5) reads, for
   // k-step t, the 16-byte k-chunk (2t + h) of its column, stored at slot (2t+h) ^ swz.
   f32x4 fa0[MI], fb0[NI], fa1[MI], fb1[NI];
-  typedef float f32x2 __attribute__((ext_vector_type(2)));
-  f32x2 fa0h = {0.f, 0.f}, fa1h = {0.f, 0.f}, fb0h[2] = {{0.f, 0.f}, {0.f, 0.f}}, fb1h[2] = {{0.f, 0.f}, {0.f, 0.f}};
-  int foff[4], foffh[4];
+  // the 16-row block: one 16-byte read per operand and HALF chunk (k-steps 2u, 2u + 1): lane (i = lane & 15,
+  // kk = lane >> 4) takes the piece 4u + kk of its column, MFMA e (two per k-step) contracts k = 16u + 4kk + e
+  f32x4 hA[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  f32x4 hB[2][2] = {{{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}};
+  int foff[4], foffh[2];
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     foff[t] = l31 * BK + 4 * ((2 * t + lh) ^ swz(l31));
-    foffh[t] = l15 * BK + 4 * ((2 * t + (lkk >> 1)) ^ swz(l15)) + 2 * (lkk & 1);
+    if (t < 2) foffh[t] = l15 * BK + 4 * ((4 * t + lkk) ^ swz(l15));
   }
   const int frag_a = 64 * wr * BK, frag_b = (SK ? 32 : 64) * wc * BK;
 #define DMDX_READ_FRAGS(FA, FB, st, t)                                               \
   do {                                                                               \
     if constexpr (H16 != 0) {                                                        \
-      const float* ah_ = lds + (st) * STG + 32 * SK * BK + foffh[t];                 \
-      const float* bh_ = lds + (st) * STG + OPA + frag_b + foffh[t];                 \
-      FA##h = *reinterpret_cast<const f32x2*>(ah_);                                  \
-      FB##h[0] = *reinterpret_cast<const f32x2*>(bh_);                               \
-      FB##h[1] = *reinterpret_cast<const f32x2*>(bh_ + 16 * BK);                     \
+      if constexpr ((t) % 2 == 0) {                                                  \
+        const float* ah_ = lds + (st) * STG + 32 * SK * BK + foffh[(t) / 2];         \
+        const float* bh_ = lds + (st) * STG + OPA + frag_b + foffh[(t) / 2];         \
+        hA[(t) / 2] = *reinterpret_cast<const f32x4*>(ah_);                          \
+        hB[(t) / 2][0] = *reinterpret_cast<const f32x4*>(bh_);                       \
+        hB[(t) / 2][1] = *reinterpret_cast<const f32x4*>(bh_ + 16 * BK);             \
+      }                                                                              \
     }                                                                                \
     const float* as_ = lds + (st) * STG + frag_a + foff[t];                          \
     const float* bs_ = lds + (st) * STG + OPA + frag_b + foff[t];                    \
@@ -488,7 +494,7 @@ __device__ __forceinline__ void tn_unit(const TnParams& p, const int split, cons
     if constexpr (H16 != 0) {                                      \
       _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_)             \
           _Pragma("unroll") for (int hh_ = 0; hh_ < 2; ++hh_) acch[hh_] = \
-              __builtin_amdgcn_mfma_f32_16x16x4f32(FA##h[s_], FB##h[hh_][s_], acch[hh_], 0, 0, 0); \
+              __builtin_amdgcn_mfma_f32_16x16x4f32(hA[(i) / 2][2 * ((i) % 2) + s_], hB[(i) / 2][hh_][2 * ((i) % 2) + s_], acch[hh_], 0, 0, 0); \
     }                                                              \
     __builtin_amdgcn_sched_group_barrier(0x008, 4 * MI * NI + 4 * H16, 0);   \
   } while (0)
@@ -505,13 +511,13 @@ __device__ __forceinline__ void tn_unit(const TnParams& p, const int split, cons
     const int phase = c & (FOLD / 4 - 1), fq = (c / (FOLD / 4)) & 3;
     DMDX_STAMP(st1);
     DMDX_READ_FRAGS(fa1, fb1, cur, 1);
-    __builtin_amdgcn_sched_group_barrier(0x100, MI + NI + 3 * H16, 0);   // ds_reads of the next fragments
+    __builtin_amdgcn_sched_group_barrier(0x100, MI + NI, 0);   // ds_reads of the next fragments (the 16-row block reads at even k-steps)
     DMDX_KSTEP(fa0, fb0, 0);
     DMDX_READ_FRAGS(fa0, fb0, cur, 2);
     __builtin_amdgcn_sched_group_barrier(0x100, MI + NI + 3 * H16, 0);
     DMDX_KSTEP(fa1, fb1, 1);
     DMDX_READ_FRAGS(fa1, fb1, cur, 3);
-    __builtin_amdgcn_sched_group_barrier(0x100, MI + NI + 3 * H16, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, MI + NI, 0);
     DMDX_KSTEP(fa0, fb0, 2);
     DMDX_STAMP(st2);
 

@@ -415,6 +415,8 @@ extern "C" int dmdx_gemm_nn_skinny_f32(const float* X, int64_t m, int64_t n, int
   hipStream_t st = (hipStream_t)stream;
   // (l <= 32 is HBM-bound: the 32x32x2 body reads 512-byte runs per column and wave-load, the
   // 16x16x4 body 256-byte runs, and streams X 4-5 % slower there: scripts/ab_k2.py)
+  // (17 <= l <= 24 as one 16-column + one or two 4-column blocks of the 16x16x4 body -- 20 or 24 columns of MFMA
+  // work instead of 32 -- was measured too: 6.09 against 5.75 ms per cfg2 pass; the 32x32x2 body is at the HBM rate there)
   if (k2_impl() == 1 && l > 32 && dmdx_skinny16_shape_ok(m, ldx)) {
     // column groups of at most 224, equally wide up to the 16-column granule; X is re-read per group
     const int64_t ng = (l + K2_GROUP - 1) / K2_GROUP;

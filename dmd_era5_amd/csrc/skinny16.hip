@@ -35,6 +35,8 @@
 // sums the slots in fp64 into G.
 #include <type_traits>
 
+#include <stdlib.h>
+
 #include "dmdx_common.h"
 
 namespace {
@@ -45,12 +47,19 @@ constexpr int KB = 32;     // k rows per W chunk
 constexpr int RW = 64;     // rows per wave
 constexpr int RWG = 256;   // rows per workgroup
 
-template <int C16, bool ALIGNED, bool GRAM, int WPS>
+// TAIL4 (0 / 1 / 2): that many 4-column blocks behind the C16 16-column blocks, on v_mfma_f32_4x4x1_16b_f32 (16
+// independent 4 x 4 x 1 products per instruction, 2 passes: the same flop rate).  Its A operand is the SAME
+// register the 16-column blocks use: lane 4 b + i of block b holds X[row 16 (b & 3) + 4 i + e][column of lane group
+// kk = b >> 2], so block b is the k-slice kk of four rows; its B operand is W[that k][16 C16 + 4 q + (lane & 3)],
+// one 16-byte LDS read per half chunk like the other fragments.  The four kk slices of a row meet in the
+// epilogue (two lane exchanges).  l = 20 runs 16 + 4 columns instead of 32, l = 50 48 + 4 instead of 64.
+template <int C16, bool ALIGNED, bool GRAM, int WPS, int TAIL4 = 0>
 __global__ __launch_bounds__(256, WPS) void skinny16_kernel(
     const float* __restrict__ X, int64_t m, int64_t n, int64_t ldx, const float* __restrict__ W,
     int64_t ldw, int l, float* __restrict__ Y, int64_t ldy, unsigned long long* clk,
     float* __restrict__ gpart) {
-  constexpr int NCOL = 16 * C16;
+  static_assert(!(GRAM && TAIL4), "the fused Gram epilogue knows 16-column blocks only");
+  constexpr int NCOL = 16 * C16 + 4 * TAIL4;
   constexpr int NP = C16 * (C16 + 1) / 2;
   constexpr int STG = NCOL * KB;                 // floats per W stage
   constexpr int G_FLOATS = GRAM ? NP * 256 : 0;
@@ -97,6 +106,11 @@ __global__ __launch_bounds__(256, WPS) void skinny16_kernel(
   for (int e = 0; e < 4; ++e)
 #pragma unroll
     for (int c = 0; c < C16; ++c) acc[e][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 acct[4][TAIL4 ? TAIL4 : 1];   // 4-column blocks: [row quad e][block q], register r = row 4 r of the lane's block
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+#pragma unroll
+    for (int q = 0; q < (TAIL4 ? TAIL4 : 1); ++q) acct[e][q] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // slow path (tail chunks, unaligned operands): kcol = the column of lane group kk = 0
   auto load_x = [&](int64_t kcol) -> f32x4 {
@@ -114,7 +128,8 @@ __global__ __launch_bounds__(256, WPS) void skinny16_kernel(
   };
 
   // W staging: 128 C16 pieces of 16 bytes per chunk, piece idx = tid + 256 i -> column idx >> 3, k-piece idx & 7
-  constexpr int NPW = (128 * C16 + 255) / 256;
+  constexpr int NPW = (8 * NCOL + 255) / 256;
+  constexpr int NPW_LAST = (8 * NCOL) % 256;   // threads with a piece in the last batch (0: all of them)
   f32x4 wreg[NPW];
   auto load_w = [&](int64_t k0) {
 #pragma unroll
@@ -149,13 +164,13 @@ __global__ __launch_bounds__(256, WPS) void skinny16_kernel(
   auto load_w_fast = [&](int64_t k0) {
 #pragma unroll
     for (int i = 0; i < NPW; ++i)
-      if ((128 * C16) % 256 == 0 || i + 1 < NPW || tid < 128)
+      if (NPW_LAST == 0 || i + 1 < NPW || tid < NPW_LAST)
         wreg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, (int)woffb[i], (int)(4 * k0), 0));
   };
   auto store_w = [&](int st) {
 #pragma unroll
     for (int i = 0; i < NPW; ++i)
-      if ((128 * C16) % 256 == 0 || i + 1 < NPW || tid < 128)
+      if (NPW_LAST == 0 || i + 1 < NPW || tid < NPW_LAST)
         *reinterpret_cast<f32x4*>(&lds[st * STG + wslot[i]]) = wreg[i];
   };
 
@@ -171,6 +186,17 @@ __global__ __launch_bounds__(256, WPS) void skinny16_kernel(
 #pragma unroll
   for (int g = 0; g < 2; ++g) foff[g] = li * KB + 4 * ((4 * g + kk) ^ ((li >> 1) & 7));
   f32x4 bb[2][PB];
+  // 4-column blocks: lane (j = lane & 3, kk) reads the piece 4 g + kk of column 16 C16 + 4 q + j, per half g
+  int fofft[2][TAIL4 ? TAIL4 : 1];
+  f32x4 bt[2][TAIL4 ? TAIL4 : 1];
+#pragma unroll
+  for (int g = 0; g < 2; ++g)
+#pragma unroll
+    for (int q = 0; q < (TAIL4 ? TAIL4 : 1); ++q) {
+      const int col = 16 * C16 + 4 * q + (li & 3);
+      fofft[g][q] = col * KB + 4 * ((4 * g + kk) ^ ((col >> 1) & 7));
+      bt[g][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
   // fragments of step k (half k / NPART, blocks PB (k % NPART) ...) from stage st into set k & 1
 #define DMDX_READ_STEP(st, k)                                                                  \
   do {                                                                                         \
@@ -178,7 +204,11 @@ __global__ __launch_bounds__(256, WPS) void skinny16_kernel(
     constexpr int hi_ = lo_ + PB < C16 ? lo_ + PB : C16;                                       \
     _Pragma("unroll") for (int c = lo_; c < hi_; ++c)                                          \
         bb[(k) & 1][c - lo_] = *reinterpret_cast<const f32x4*>(&lds[(st) * STG + 16 * c * KB + foff[g_]]); \
-    __builtin_amdgcn_sched_group_barrier(0x100, hi_ - lo_, 0);                                 \
+    if constexpr (TAIL4 != 0 && (k) % NPART == 0) {                                            \
+      _Pragma("unroll") for (int q = 0; q < TAIL4; ++q)                                        \
+          bt[g_][q] = *reinterpret_cast<const f32x4*>(&lds[(st) * STG + fofft[g_][q]]);        \
+    }                                                                                          \
+    __builtin_amdgcn_sched_group_barrier(0x100, hi_ - lo_ + ((k) % NPART == 0 ? TAIL4 : 0), 0); \
   } while (0)
   // the MFMAs of step k: 4 k-steps x 4 row blocks x its column blocks, on the 4 X quads of its half
 #if defined(DMDX_K2_ABL) && (DMDX_K2_ABL & 1)   /* timing only: no MFMAs */
@@ -197,7 +227,13 @@ __global__ __launch_bounds__(256, WPS) void skinny16_kernel(
         _Pragma("unroll") for (int e = 0; e < 4; ++e)                                          \
             _Pragma("unroll") for (int c = lo_; c < hi_; ++c) acc[e][c] =                      \
                 __builtin_amdgcn_mfma_f32_16x16x4f32(xq[g_][s][e], bb[(k) & 1][c - lo_][s], acc[e][c], 0, 0, 0); \
-    __builtin_amdgcn_sched_group_barrier(0x008, 16 * (hi_ - lo_), 0);                          \
+    if constexpr (TAIL4 != 0 && (k) % NPART == 0) {                                            \
+      _Pragma("unroll") for (int s = 0; s < 4; ++s)                                            \
+          _Pragma("unroll") for (int e = 0; e < 4; ++e)                                        \
+              _Pragma("unroll") for (int q = 0; q < TAIL4; ++q) acct[e][q] =                   \
+                  __builtin_amdgcn_mfma_f32_4x4x1f32(xq[g_][s][e], bt[g_][q][s], acct[e][q], 0, 0, 0); \
+    }                                                                                          \
+    __builtin_amdgcn_sched_group_barrier(0x008, 16 * (hi_ - lo_) + ((k) % NPART == 0 ? 16 * TAIL4 : 0), 0); \
   } while (0)
 #endif
 
@@ -324,6 +360,35 @@ __global__ __launch_bounds__(256, WPS) void skinny16_kernel(
     }
   }
 
+  if constexpr (TAIL4 != 0) {
+    // block b = lane >> 2 of a 4-column result is the k-slice kk = b >> 2 of the rows 16 (b & 3) + 4 r + e: the four
+    // slices sit 16 lanes apart; lanes kk = 0 store the sums
+#pragma unroll
+    for (int q = 0; q < TAIL4; ++q) {
+      const int col = 16 * C16 + 4 * q + (li & 3);
+      float* yc = Y + (int64_t)(col < l ? col : 0) * ldy;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        f32x4 v = {acct[0][q][r], acct[1][q][r], acct[2][q][r], acct[3][q][r]};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] += __shfl_xor(v[e], 16, 64);
+          v[e] += __shfl_xor(v[e], 32, 64);
+        }
+        const int64_t row = rowW + 16 * (li >> 2) + 4 * r;
+        if (kk == 0 && col < l) {
+          if (ALIGNED && row + 4 <= m) {
+            *reinterpret_cast<f32x4*>(yc + row) = v;
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (row + e < m) yc[row + e] = v[e];
+          }
+        }
+      }
+    }
+  }
+
   if constexpr (GRAM) {
     // rows past the end hold clamped duplicates, columns >= l copies of column l - 1: not part of Y
     if (rowW + RW > m) {
@@ -420,7 +485,7 @@ __global__ __launch_bounds__(256) void skinny16_gram_reduce_kernel(const float* 
   }
 }
 
-template <int C16, bool GRAM>
+template <int C16, bool GRAM, int TAIL4 = 0>
 int launch16(const float* X, int64_t m, int64_t n, int64_t ldx, const float* W, int64_t ldw, int l, float* Y,
              int64_t ldy, hipStream_t stream, float* gpart, double* G, int64_t ldg, int accumulate) {
   const bool aligned = (m % 4 == 0) && (m >= 4) && (ldx % 4 == 0) && (ldw % 4 == 0) && (ldy % 4 == 0) &&
@@ -429,10 +494,10 @@ int launch16(const float* X, int64_t m, int64_t n, int64_t ldx, const float* W, 
   constexpr int WPS = (C16 <= 7) ? 2 : 1;
   dim3 grid((unsigned)((m + RWG - 1) / RWG));
   if (aligned)
-    hipLaunchKernelGGL((skinny16_kernel<C16, true, GRAM, WPS>), grid, dim3(256), 0, stream, X, m, n, ldx, W, ldw, l, Y,
+    hipLaunchKernelGGL((skinny16_kernel<C16, true, GRAM, WPS, TAIL4>), grid, dim3(256), 0, stream, X, m, n, ldx, W, ldw, l, Y,
                        ldy, dmdx_clock_probe_ptr, gpart);
   else
-    hipLaunchKernelGGL((skinny16_kernel<C16, false, GRAM, WPS>), grid, dim3(256), 0, stream, X, m, n, ldx, W, ldw, l, Y,
+    hipLaunchKernelGGL((skinny16_kernel<C16, false, GRAM, WPS, TAIL4>), grid, dim3(256), 0, stream, X, m, n, ldx, W, ldw, l, Y,
                        ldy, dmdx_clock_probe_ptr, gpart);
   DMDX_LAUNCH_CHECK();
   if constexpr (GRAM) {
@@ -458,7 +523,28 @@ int dispatch16(int c16, const float* X, int64_t m, int64_t n, int64_t ldx, const
   return DMDX_E_INVALID;
 }
 
+// 16 c16 + 4 t4 columns (t4 = 1, 2; c16 <= 4: l = 17 .. 72 with l % 16 in 1 .. 8), no fused Gram
+int dispatch16_tail(int c16, int t4, const float* X, int64_t m, int64_t n, int64_t ldx, const float* W, int64_t ldw,
+                    int l, float* Y, int64_t ldy, hipStream_t st) {
+#define DMDX_CASE(C, T) \
+  if (c16 == C && t4 == T) return launch16<C, false, T>(X, m, n, ldx, W, ldw, l, Y, ldy, st, nullptr, nullptr, 0, 0)
+  DMDX_CASE(1, 1); DMDX_CASE(1, 2); DMDX_CASE(2, 1); DMDX_CASE(2, 2);
+  DMDX_CASE(3, 1); DMDX_CASE(3, 2); DMDX_CASE(4, 1); DMDX_CASE(4, 2);
+#undef DMDX_CASE
+  dmdx_set_error("skinny16: no 4-column-block kernel for %d + %d blocks", c16, t4);
+  return DMDX_E_INVALID;
+}
+
 }  // namespace
+
+// columns the 16 + 4 granular body runs for l (0: not eligible -- l <= 16, more than 8 columns past a multiple of
+// 16, or beyond the instantiated sizes)
+static int tail_blocks(int l) {
+  if (getenv("DMDX_K2_NO_TAIL") != nullptr) return 0;
+  const int rem = l % 16;
+  if (l <= 16 || l > 72 || rem == 0 || rem > 8) return 0;
+  return (rem + 3) / 4;
+}
 
 bool dmdx_skinny16_shape_ok(int64_t m, int64_t ldx) {
   return ldx < (int64_t(1) << 23) && m + 12 * ldx < (int64_t(1) << 29);
@@ -466,6 +552,7 @@ bool dmdx_skinny16_shape_ok(int64_t m, int64_t ldx) {
 
 int dmdx_skinny16_launch(const float* X, int64_t m, int64_t n, int64_t ldx, const float* W, int64_t ldw, int l, float* Y,
                          int64_t ldy, hipStream_t st) {
+  if (const int t4 = tail_blocks(l)) return dispatch16_tail(l / 16, t4, X, m, n, ldx, W, ldw, l, Y, ldy, st);
   return dispatch16<false>((l + 15) / 16, X, m, n, ldx, W, ldw, l, Y, ldy, st, nullptr, nullptr, 0, 0);
 }
 

@@ -113,7 +113,10 @@ def test_gemm_tn(K, K_, na, nb):
      # round 3, the 16x16x4 body: 16-column granules (l = 70 runs 80 columns, 72 -> 80, 80 -> 80), one pass up
      # to 224 columns, two column groups above, rows that are no multiple of 256 / 64 / 4, n % 32 != 0
      (8192, 3653, 80), (5000, 100, 72), (3000, 257, 220), (2048, 130, 224), (1030, 64, 256), (2050, 96, 300),
-     (7, 5, 3), (1001, 37, 70), (70000, 61, 17), (263, 31, 209)],
+     (7, 5, 3), (1001, 37, 70), (70000, 61, 17), (263, 31, 209),
+     # 4-column blocks behind the 16-column ones (33 <= l <= 72, l % 16 in 1 .. 8): 36 = 32 + 4, 40 = 32 + 8,
+     # 52 = 48 + 4, 65 -> 68, 33 -> 36; ragged rows and n % 32 != 0
+     (1000, 40, 36), (4099, 130, 40), (2051, 301, 52), (70003, 61, 65), (6, 9, 33), (12288, 3653, 56)],
 )
 def test_skinny(K, m, n, l):
     rs = np.random.RandomState(m + 13 * n + 7 * l)
@@ -134,7 +137,7 @@ def test_skinny(K, m, n, l):
                                    (66000, 40, 150), (5, 3, 2)])
 def test_skinny_with_fused_gram(K, m, n, l):
     """K2 with the Gram of its output formed from the accumulators in the same launch: Y must be
-    bit-identical to the plain K2 launch and G = Y^T Y (of the stored fp32 Y, fp64 reference)
+    bit-identical to the plain K2 launch (where both run the same blocks) and G = Y^T Y (of the stored fp32 Y, fp64 reference)
     within 4e-6 sum|y||y| (fp32 MFMA chains of 128 rows, fp64 across waves and workgroups) --
     including row counts that are not multiples of 512 / 128 / 4 (the clamped rows past the end
     must not be counted), l not a multiple of 32, and accumulation over row blocks."""
@@ -145,7 +148,13 @@ def test_skinny_with_fused_gram(K, m, n, l):
     Y0 = K.skinny(Xt, Wt)
     G = torch.zeros((l, l), dtype=torch.float64, device="cuda")
     Y1 = K.skinny(Xt, Wt, gram=G)
-    assert torch.equal(Y0, Y1)
+    if 32 < l <= 72 and 1 <= l % 16 <= 8:
+        # the plain launch runs the last columns on 4-column blocks (another summation order over k):
+        # the same product to fp32 rounding, not bit for bit
+        absref = (np.abs(X).astype(np.float64) @ np.abs(W).astype(np.float64)).T
+        assert np.all(np.abs(Y0.cpu().numpy().astype(np.float64) - Y1.cpu().numpy()) <= 2 * (4 + np.sqrt(n)) * EPS32 * absref + 1e-30)
+    else:
+        assert torch.equal(Y0, Y1)
     Yd = Y1.double()
     ref = Yd @ Yd.T
     bound = 4e-6 * (Yd.abs() @ Yd.abs().T) + 1e-30

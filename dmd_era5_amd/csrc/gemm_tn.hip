@@ -979,6 +979,14 @@ __device__ __forceinline__ void xty_dma(unsigned lds_addr, unsigned off, const c
                :: "s"(lds_addr), "v"(off), "s"(base) : "memory");
 }
 
+// T4 < 0: the body described above (32 rows of D on v_mfma_f32_32x32x2_f32).
+// T4 = 0 / 1 / 2 (nb <= 16 / 20 / 24, round 3): 16 rows of D on v_mfma_f32_16x16x4_f32 -- lane (i, kk) reads the piece
+//   4 wave + kk of its column: MFMA e contracts the wave's rows 16 wave + 4 kk + e -- and T4 groups of 4 more rows on
+//   v_mfma_f32_4x4x1_16b_f32 with the sixteen blocks of an instruction on sixteen groups of 4 time columns: A = X[row]
+//   [64 h + lane], B = Y[row][16 + 4 q + (lane & 3)], one row per instruction, 4 accumulator registers per 64 time
+//   columns and no cross-lane sum.  The reference's default rank (l = 20) executes 20 columns of MFMA work per
+//   X element instead of 32: PMC had the 32-column body at 79 % matrix-core occupancy under a 5.5 TB/s stream.
+template <int T4>
 __global__ __launch_bounds__(NTH, 2) void xty_small_kernel(XtyBatch bt) {
   __shared__ __attribute__((aligned(16))) float lds[2 * XSTG];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1027,6 +1035,94 @@ __global__ __launch_bounds__(NTH, 2) void xty_small_kernel(XtyBatch bt) {
     for (int i = 0; i < 8; ++i) xty_dma((unsigned)(uintptr_t)DMDX_LDS_PTR(xs + 4 * i * XK), xoff[i], xb);
   };
 
+  if constexpr (T4 >= 0) {
+    constexpr int NT = T4 > 0 ? T4 : 1;
+    const int c15 = lane & 15, kk = lane >> 4;
+    f32x4 a16[8], a16b[8], at[2][NT], atb[2][NT];
+#pragma unroll
+    for (int b = 0; b < 8; ++b) { a16[b] = f32x4{0.f, 0.f, 0.f, 0.f}; a16b[b] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int q = 0; q < NT; ++q) { at[h][q] = f32x4{0.f, 0.f, 0.f, 0.f}; atb[h][q] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    if (nch > 0) issue(0, 0);
+    if (nch > 1) issue(1, 1);
+    const int ko16 = 4 * ((4 * wave + kk) ^ c15);          // the 16-column operands: piece 4 wave + kk of column c15 (+ 16 b)
+    for (int c = 0; c < nch; ++c) {
+      const int st = c & 1;
+      if (c + 1 < nch) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      const float* ys = lds + st * XSTG;
+      const float* xs = ys + XL * XK;
+      const f32x4 fa = *reinterpret_cast<const f32x4*>(ys + c15 * XK + ko16);
+      f32x4 fb[8];
+#pragma unroll
+      for (int b = 0; b < 8; ++b) fb[b] = *reinterpret_cast<const f32x4*>(xs + (16 * b + c15) * XK + ko16);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int b = 0; b < 8; ++b) a16[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[e], fb[b][e], a16[b], 0, 0, 0);
+      if constexpr (T4 > 0) {
+#pragma unroll
+        for (int p4 = 0; p4 < 4; ++p4) {                     // rows 16 wave + 4 p4 + e
+          f32x4 ax[2], by[NT];
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+            ax[h] = *reinterpret_cast<const f32x4*>(xs + (64 * h + lane) * XK + 4 * ((4 * wave + p4) ^ (lane & 15)));
+#pragma unroll
+          for (int q = 0; q < NT; ++q) {
+            const int yc = 16 + 4 * q + (lane & 3);
+            by[q] = *reinterpret_cast<const f32x4*>(ys + yc * XK + 4 * ((4 * wave + p4) ^ (yc & 15)));
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+              for (int q = 0; q < NT; ++q) at[h][q] = __builtin_amdgcn_mfma_f32_4x4x1f32(ax[h][e], by[q][e], at[h][q], 0, 0, 0);
+        }
+      }
+      __syncthreads();   // every wave has read stage st for the last time
+      if (c + 2 < nch) issue(c + 2, st);
+      if ((c & (XFOLD - 1)) == XFOLD - 1) {
+#pragma unroll
+        for (int b = 0; b < 8; ++b) { a16b[b] += a16[b]; a16[b] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int q = 0; q < NT; ++q) { atb[h][q] += at[h][q]; at[h][q] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      }
+    }
+    // ---- this wave's 32 x 128 image: rows 0..15 from the 16 x 16 results (lane (j, q), register r: row 4 q + r,
+    // column 16 b + j), rows 16 + 4 q + (lane & 3) from the 4 x 4 blocks (register i: column 64 h + 4 (lane >> 2) + i),
+    // the rest zero
+    float* red = lds + wave * (XL * XT);
+#pragma unroll
+    for (int b = 0; b < 8; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[(4 * kk + r) * XT + 16 * b + c15] = a16[b][r] + a16b[b][r];
+    for (int o = 4 * lane; o < 16 * XT; o += 256)            // rows 16 .. 31
+      *reinterpret_cast<f32x4*>(red + 16 * XT + o) = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (T4 > 0) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the wave's own zeros before its own values: same addresses)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int q = 0; q < NT; ++q) {
+          const f32x4 v = at[h][q] + atb[h][q];
+          *reinterpret_cast<f32x4*>(red + (16 + 4 * q + (lane & 3)) * XT + 64 * h + 4 * (lane >> 2)) = v;
+        }
+    }
+    __syncthreads();
+    double* Pt = bt.P + (size_t)u * (XL * XT);
+    const float* r0 = lds;
+    for (int o = tid; o < XL * XT; o += NTH) {
+      const double v = (double)r0[o] + (double)r0[XL * XT + o] + (double)r0[2 * XL * XT + o] + (double)r0[3 * XL * XT + o];
+      __builtin_nontemporal_store(v, Pt + o);
+    }
+    return;
+  }
   f32x16 acc[4], acc2[4];
 #pragma unroll
   for (int b = 0; b < 4; ++b)
@@ -1183,7 +1279,12 @@ int run_xty_small(const float* const* X, const int64_t* ldx, const float* const*
     bt.nb = (int)nb;
     bt.P = reinterpret_cast<double*>(ws);
     if (units > 0) {   // (a group of blocks that are all shorter than one chunk: the reduce kernel still defines D)
-      hipLaunchKernelGGL(xty_small_kernel, dim3((unsigned)units), dim3(NTH), 0, stream, bt);
+      // (16 + 4 T4 rows of MFMA work for nb <= 16 / 20 / 24; DMDX_K3S_32=1: the 32-row body for everything, A/B)
+      const bool wide = nb > 24 || getenv("DMDX_K3S_32") != nullptr;
+      if (wide) hipLaunchKernelGGL(xty_small_kernel<-1>, dim3((unsigned)units), dim3(NTH), 0, stream, bt);
+      else if (nb <= 16) hipLaunchKernelGGL(xty_small_kernel<0>, dim3((unsigned)units), dim3(NTH), 0, stream, bt);
+      else if (nb <= 20) hipLaunchKernelGGL(xty_small_kernel<1>, dim3((unsigned)units), dim3(NTH), 0, stream, bt);
+      else hipLaunchKernelGGL(xty_small_kernel<2>, dim3((unsigned)units), dim3(NTH), 0, stream, bt);
       DMDX_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(xty_small_reduce_kernel, dim3((unsigned)ntiles, (unsigned)nb), dim3(XT), 0, stream, bt, D64, ld64,

@@ -23,7 +23,7 @@ def run(l, tm):
     os.environ.pop("DMDX_TN_FORCE_TM", None)
     return statistics.median(ts)
 print(f"{NB} blocks of {mb} x {n} ({NB*mb*n*4/1e9:.1f} GB per pass)")
-cases = [(20, (0,)), (32, (0,)), (60, (0,)), (70, (0,)), (120, (0,))] if os.environ.get("AB_K3_SHAPE") == "cfg2" else \
+cases = [(10, (0,)), (16, (0,)), (20, (0,)), (24, (0,)), (32, (0,)), (60, (0,))] if os.environ.get("AB_K3_SHAPE") == "cfg2" else \
     [(40, (64, 48)), (60, (64,)), (70, (96, 80)), (80, (96, 80)), (100, (128, 112)), (220, (0,))]
 for l, tms in cases:
     for tm in tms:

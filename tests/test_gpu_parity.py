@@ -823,7 +823,10 @@ def test_gemm_tn_blocks_equals_sum_of_block_products(K, sizes, na, nb):
 
 
 @pytest.mark.parametrize("sizes,na,nb", [([4096, 4096], 300, 20), ([5000, 3001, 4097], 260, 32), ([640] * 19, 129, 7),
-                                         ([30001, 29999], 1000, 1), ([129780, 129780], 8760, 20), ([70000], 515, 10)])
+                                         ([30001, 29999], 1000, 1), ([129780, 129780], 8760, 20), ([70000], 515, 10),
+                                         # round 3: 16 rows on 16x16x4 + 0 / 1 / 2 groups of 4 rows on 4x4x1 (nb <= 16 / 20 / 24)
+                                         ([4096, 4160], 300, 16), ([5000, 3001], 260, 17), ([6400, 6400, 130], 131, 21),
+                                         ([8192] * 3, 1000, 24), ([4099, 4100], 64 + 128, 18), ([12800, 6400], 8760, 25)])
 def test_gemm_tn_blocks_small_l_path(K, sizes, na, nb):
     """nb <= 32 takes K3s (64-row chunks, waves split the rows of a chunk): against the fp64 product
     of the stacked rows with the bound of the generic path; block lengths that are not multiples

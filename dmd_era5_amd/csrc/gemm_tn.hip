@@ -169,7 +169,7 @@ __device__ inline f32x4 load4_tail(const float* p, int64_t k, int64_t kend) {
 // all waves: [0] DMA issue, [1] fragment reads + MFMA issue, [5] wait for the LDS-DMA (vmcnt),
 // [2] barrier, [3] post-barrier (first fragment read, fold), [4] chunks counted,
 // [6] / [7] chunk-loop time in core cycles / in 100 MHz ticks (their ratio = sustained clock)
-__device__ unsigned long long dmdx_stamp[8];
+__device__ unsigned long long dmdx_stamp[12];   // [8] unit prologue, [9] partial-tile commit (stores drained), [10] waves counted
 #define DMDX_STAMP(var)                                                        \
   do {                                                                         \
     __builtin_amdgcn_sched_barrier(0);                                         \
@@ -206,6 +206,10 @@ template <bool DMA, int ABL, int SK, int H16 = 0>
 __device__ __forceinline__ void tn_unit(const TnParams& p, const int split, const int row0, const int col0,
                                         double* Pt, float* lds) {
   static_assert(!H16 || SK >= 1, "a 16-row block only below at least one 32-row block");
+#ifdef DMDX_STAMPS
+  unsigned long long pt0;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pt0)::"memory");
+#endif
   constexpr int TM = SK ? 32 * SK + 16 * H16 : BT;  // tile rows    (columns of OpA)
   constexpr int MI = SK ? SK : 2;        // 32-row MFMA blocks per wave
   constexpr int NI = SK ? 1 : 2;         // 32-column MFMA blocks per wave
@@ -564,9 +568,18 @@ __device__ __forceinline__ void tn_unit(const TnParams& p, const int split, cons
     atomicAdd(&dmdx_stamp[6], st4 - ct0);   // core-clock cycles of this wave's chunk loop
     atomicAdd(&dmdx_stamp[7], rt1 - rt0);   // the same interval in 100 MHz reference ticks
     atomicAdd(&dmdx_stamp[4], (unsigned long long)nchunks);
+    atomicAdd(&dmdx_stamp[8], ct0 - pt0);
+    atomicAdd(&dmdx_stamp[10], 1ull);
   }
 #endif
   DMDX_COMMIT_ALL();
+#ifdef DMDX_STAMPS
+  {
+    unsigned long long et1;
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(et1)::"memory");
+    if (lane == 0) atomicAdd(&dmdx_stamp[9], et1 - st4);
+  }
+#endif
 #undef DMDX_READ_FRAGS
 #undef DMDX_MFMA4
 #undef DMDX_KSTEP
@@ -1315,9 +1328,9 @@ extern "C" {
 
 #ifdef DMDX_STAMPS
 int dmdx_debug_read_stamps(unsigned long long* out8, int reset) {
-  hipError_t e = hipMemcpyFromSymbol(out8, HIP_SYMBOL(dmdx_stamp), 8 * sizeof(unsigned long long));
+  hipError_t e = hipMemcpyFromSymbol(out8, HIP_SYMBOL(dmdx_stamp), 12 * sizeof(unsigned long long));   // (12 entries)
   if (reset) {
-    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long z[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     (void)hipMemcpyToSymbol(HIP_SYMBOL(dmdx_stamp), z, sizeof(z));
   }
   return (int)e;

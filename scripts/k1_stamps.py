@@ -6,7 +6,7 @@ from dmd_era5_amd import _lib
 K = default_kernels(); lib = _lib.load()
 g = torch.Generator(device="cuda").manual_seed(1)
 Xt = torch.randn((8760, 129780), generator=g, device="cuda")
-buf = (C.c_ulonglong * 8)()
+buf = (C.c_ulonglong * 12)()
 K.syrk(Xt); torch.cuda.synchronize(); lib.dmdx_debug_read_stamps(buf, 1)
 K.syrk(Xt); torch.cuda.synchronize(); lib.dmdx_debug_read_stamps(buf, 1)
 n = buf[4]

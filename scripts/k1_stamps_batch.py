@@ -11,7 +11,7 @@ g = torch.Generator(device="cuda").manual_seed(1)
 NB = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 blocks = [torch.randn((8760, 129780), generator=g, device="cuda") for _ in range(NB)]
 out = torch.empty((8760, 8760), dtype=torch.float64, device="cuda")
-buf = (C.c_ulonglong * 8)()
+buf = (C.c_ulonglong * 12)()
 for _ in range(2):
     K.syrk_blocks(blocks, out=out); torch.cuda.synchronize(); lib.dmdx_debug_read_stamps(buf, 1)
 K.events = []
@@ -25,3 +25,5 @@ units = 2415 * 2 * NB
 print(f"{NB} blocks: launch + reduce {ms:.1f} ms; {n} wave-chunks at {per:.0f} cycles (2 x 4096 = the matrix core) and {clock:.0f} MHz "
       f"= {loop_ms:.1f} ms inside the chunk loops ({100 * loop_ms / ms:.1f} %); outside them {ms - loop_ms:.1f} ms = "
       f"{1e3 * (ms - loop_ms) * 512 / units:.0f} us per unit ({units} units, 512 resident, {units / 512:.2f} rounds)")
+print(f"per wave and unit: prologue {buf[8] / max(buf[10], 1) / clock:.1f} us, partial-tile commit (stores drained) {buf[9] / max(buf[10], 1) / clock:.1f} us, "
+      f"chunk loop {buf[6] / max(buf[10], 1) / clock / 1e3:.3f} ms")

@@ -16,7 +16,7 @@ if nb:
     call = lambda: K.gemm_tn_blocks(Xs, Ys)
 else:
     call = lambda: K.gemm_tn(Yt, Xt)
-buf = (C.c_ulonglong * 8)()
+buf = (C.c_ulonglong * 12)()
 for _ in range(2):
     call(); torch.cuda.synchronize(); lib.dmdx_debug_read_stamps(buf, 1)
 K.events = []

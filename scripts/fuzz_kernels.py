@@ -28,7 +28,7 @@ def check(name, got, ref, absref, tol=2e-6):
 
 for i in range(N):
     m = int(rs.choice([1, 5, 31, 32, 33, 127, 129, 1000, 4097, 30001])); n = int(rs.choice([1, 2, 31, 64, 65, 128, 129, 260, 500]))
-    l = int(rs.choice([1, 2, 31, 32, 33, 64, 65, 100, 128, 130, 200]))
+    l = int(rs.choice([1, 2, 16, 17, 20, 24, 25, 31, 32, 33, 36, 50, 64, 65, 70, 72, 100, 128, 130, 200]))
     if i % 100 == 99:
         print("...", i + 1, "rounds,", bad, "flagged so far", flush=True)
     try:
